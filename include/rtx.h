@@ -1,0 +1,286 @@
+/*
+ * rtx.h — C ABI of the MI355X (gfx950) render path.
+ *
+ * This is the drop-in boundary for the one hot path of clayne/CPU-Raytracer:
+ *
+ *   Raytracer::render_tile -> Raytracer::bounce -> Scene::trace_primitives /
+ *   Scene::intersect_primitives -> TopLevelBVH / Mesh / BottomLevelBVH ->
+ *   triangle / Sphere / Plane tests -> Light::calc_lighting -> recursive
+ *   reflect / refract with ray differentials -> Texture::sample / Sky::sample
+ *   -> Window::plot
+ *
+ * The reference has no FFI of its own; its seam is three C++ entry points
+ * (reference file:line given with each function below).  Every function here
+ * takes plain pointers and sizes only, returns an int status (RTX_OK == 0)
+ * instead of the reference's printf + abort(), copies caller-owned host
+ * buffers before returning, and is implemented by librtx_hip.so (hand-written
+ * HIP for gfx950).  There is no CPU fallback behind this ABI: without a HIP
+ * device rtx_create() fails with RTX_ERR_NO_DEVICE.
+ *
+ * Record layouts marked "reference layout" are byte-identical to the
+ * reference's lane-1 structs so that its flattened BottomLevelBVH arrays and
+ * its `.bvh` cache files (BottomLevelBVH.cpp:149-192) can be handed over
+ * without conversion.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_ABI_VERSION 1
+
+/* ---- status codes (the reference aborts; we return) -------------------- */
+enum {
+    RTX_OK               = 0,
+    RTX_ERR_INVALID_ARG  = 1,  /* null pointer, negative count, bad id      */
+    RTX_ERR_NO_DEVICE    = 2,  /* no HIP device / device ordinal not present */
+    RTX_ERR_HIP          = 3,  /* a HIP runtime call failed (see rtx_last_error) */
+    RTX_ERR_LIMIT        = 4,  /* MAX_MATERIALS (Config.h:18), stack size, texture count ... */
+    RTX_ERR_STATE        = 5,  /* render before set_frame / missing BLAS ...  */
+    RTX_ERR_OOM          = 6
+};
+
+/* ---- Config.h knobs (reference Config.h:1-55) --------------------------- */
+enum { RTX_TRAVERSE_NAIVE = 0, RTX_TRAVERSE_ORDERED = 1 };            /* Config.h:27-30 */
+enum { RTX_TEXTURE_NEAREST = 0, RTX_TEXTURE_BILINEAR = 1, RTX_TEXTURE_MIPMAP = 2 }; /* Config.h:38-42 */
+enum { RTX_MIP_TRILINEAR = 0, RTX_MIP_ANISOTROPIC = 1, RTX_MIP_EWA = 2 };           /* Config.h:49-53 */
+
+#define RTX_MAX_MATERIALS   256   /* Config.h:18  MAX_MATERIALS            */
+#define RTX_MAX_STACK       64    /* Config.h:25  BVH_TRAVERSAL_STACK_SIZE */
+#define RTX_MAX_MIP_LEVELS  16
+#define RTX_TILE_SIZE       32    /* Window.h:32-33 tile_width/tile_height */
+#define RTX_EWA_LUT_SIZE    128   /* Texture.h:53                          */
+
+typedef struct rtx_config {
+    int32_t width;               /* SCREEN_WIDTH                                    */
+    int32_t height;              /* SCREEN_HEIGHT                                   */
+    int32_t bounces;             /* NUMBER_OF_BOUNCES (0 = primary rays only)       */
+    int32_t stack_size;          /* BVH_TRAVERSAL_STACK_SIZE, 1..RTX_MAX_STACK      */
+    int32_t traversal_strategy;  /* BVH_TRAVERSAL_STRATEGY                          */
+    int32_t texture_mode;        /* TEXTURE_SAMPLE_MODE                             */
+    int32_t mip_filter;          /* MIPMAP_FILTER                                   */
+    float   max_anisotropy;      /* MAX_ANISOTROPY                                  */
+    int32_t device;              /* HIP device ordinal for this context             */
+    int32_t reserved[7];
+} rtx_config;
+
+/* ---- geometry records (reference layouts) ------------------------------ */
+typedef struct rtx_bvh_node {          /* BVHNode.h:10-16, 32 B */
+    float   aabb_min[3];
+    float   aabb_max[3];
+    int32_t left_or_first;             /* inner: index of left child (right = left+1); leaf: first primitive */
+    int32_t count;                     /* bits 30-31: split axis (1=x,2=y,3=z); bits 0-29: leaf count (>0 = leaf) */
+} rtx_bvh_node;
+
+typedef struct rtx_triangle_hot {      /* BottomLevelBVH.h:6-10, 36 B */
+    float position_0[3];
+    float position_edge_1[3];
+    float position_edge_2[3];
+} rtx_triangle_hot;
+
+typedef struct rtx_triangle_cold {     /* BottomLevelBVH.h:12-22, 64 B */
+    float   tex_coord_0[2];
+    float   tex_coord_edge_1[2];
+    float   tex_coord_edge_2[2];
+    float   normal_0[3];
+    float   normal_edge_1[3];
+    float   normal_edge_2[3];
+    int32_t material_id;               /* OBJ-local id; global id = material_offset + this (BottomLevelBVH.cpp:265) */
+} rtx_triangle_cold;
+
+typedef struct rtx_material {          /* Material.h:7-14 (texture pointer replaced by a texture id) */
+    float   diffuse[3];
+    int32_t texture_id;                /* -1 = no texture */
+    float   reflection[3];
+    float   transmittance[3];
+    float   index_of_refraction;
+    int32_t pad;
+} rtx_material;                        /* 48 B */
+
+typedef struct rtx_texture_desc {      /* Texture.h:8-19 */
+    int32_t width;
+    int32_t height;
+    int32_t mipmapped;                 /* Texture.cpp:49-55: both sides powers of two and mipmap mode */
+    int32_t mip_levels;                /* 1 when not mipmapped */
+    int32_t mip_offsets[RTX_MAX_MIP_LEVELS]; /* in texels, Texture.cpp:76-117 */
+} rtx_texture_desc;
+
+typedef struct rtx_instance {          /* Mesh.h:8-14 after Mesh::update (Mesh.cpp:9-15) */
+    int32_t blas_id;
+    int32_t pad[3];
+    float   world[16];                 /* Transform::world_matrix, cells[i + 4*j] (Matrix4.h:19-23) */
+    float   world_inv[16];             /* Mesh::transform_inv */
+} rtx_instance;
+
+typedef struct rtx_sphere {            /* Sphere.h:7-24 after Sphere::update */
+    float   center[3];                 /* transform.position */
+    float   radius_inv;
+    float   radius_squared;
+    int32_t material_id;               /* global material id (Primitive.h:6) */
+} rtx_sphere;
+
+typedef struct rtx_plane {             /* Plane.h:7-22 after Plane::update (Plane.cpp:3-11) */
+    float   normal[3];                 /* world_normal */
+    float   distance;                  /* world_distance */
+    float   u_axis[3];
+    float   v_axis[3];
+    int32_t material_id;
+    int32_t pad;
+} rtx_plane;
+
+typedef struct rtx_point_light {       /* PointLight.h:4-7 */
+    float colour[3];
+    float position[3];
+} rtx_point_light;
+
+typedef struct rtx_spot_light {        /* SpotLight.h:6-15 */
+    float colour[3];
+    float position[3];
+    float negative_direction[3];
+    float inner_cutoff;                /* cos(half inner angle) */
+    float outer_cutoff;                /* cos(half outer angle) */
+} rtx_spot_light;
+
+typedef struct rtx_directional_light { /* DirectionalLight.h:4-7 */
+    float colour[3];
+    float negative_direction[3];
+} rtx_directional_light;
+
+typedef struct rtx_camera {            /* Camera.h:10-23 after Camera::update (Camera.cpp:44-47) */
+    float position[3];
+    float rotated_top_left_corner[3];
+    float rotated_x_axis[3];
+    float rotated_y_axis[3];
+} rtx_camera;
+
+/* Everything Scene::update (Scene.cpp:139-171) produces for one frame. */
+typedef struct rtx_frame {
+    rtx_camera camera;
+    float      ambient[3];             /* Scene::ambient_lighting (Scene.h:33) */
+    int32_t    pad0;
+
+    const rtx_bvh_node * tlas_nodes;   /* TopLevelBVH::nodes (root = 0, index 1 unused) */
+    int32_t              tlas_node_count;
+    const int32_t *      tlas_indices; /* TopLevelBVH::indices: leaf slot -> instance */
+    int32_t              tlas_index_count;
+    const rtx_instance * instances;
+    int32_t              instance_count;
+
+    const rtx_sphere * spheres;                     int32_t sphere_count;
+    const rtx_plane *  planes;                      int32_t plane_count;
+    const rtx_point_light *       point_lights;       int32_t point_light_count;
+    const rtx_spot_light *        spot_lights;        int32_t spot_light_count;
+    const rtx_directional_light * directional_lights; int32_t directional_light_count;
+} rtx_frame;
+
+/* PerformanceStats (Raytracer.h:4-9), widened to 64 bit; counting rule of
+ * Raytracer.cpp:61,163,180,192,265,320 at SIMD_LANE_SIZE == 1.            */
+typedef struct rtx_stats {
+    uint64_t num_primary_rays;
+    uint64_t num_shadow_rays;
+    uint64_t num_reflection_rays;
+    uint64_t num_refraction_rays;
+} rtx_stats;
+
+/* Work counters behind the roofline accounting; filled by
+ * rtx_render_tiles only when RTX_RENDER_COUNT_WORK is set (slower kernels). */
+typedef struct rtx_work_counters {
+    uint64_t closest_rays;             /* rays through trace_primitives          */
+    uint64_t any_rays;                 /* rays through intersect_primitives      */
+    uint64_t tlas_nodes_closest;       /* TLAS nodes popped (slab tests)         */
+    uint64_t tlas_nodes_any;
+    uint64_t blas_nodes_closest;       /* BLAS nodes popped (slab tests)         */
+    uint64_t blas_nodes_any;
+    uint64_t instances_closest;        /* Mesh::trace entered                    */
+    uint64_t instances_any;            /* Mesh::intersect entered                */
+    uint64_t tri_tests_closest;        /* triangle_trace calls                   */
+    uint64_t tri_tests_any;            /* triangle_intersect calls               */
+    uint64_t triangle_hits;            /* closest hit is a triangle (cold fetch) */
+    uint64_t shaded_hits;              /* material fetches                       */
+    uint64_t sky_lookups;
+    uint64_t texel_fetches;
+    uint64_t rays_spawned;             /* secondary rays written to a queue      */
+    uint64_t reserved[5];
+} rtx_work_counters;
+
+typedef struct rtx_ctx rtx_ctx;
+
+/* ---- lifetime ----------------------------------------------------------- */
+
+/* One context per GPU.  Replaces: Window(SCREEN_WIDTH, SCREEN_HEIGHT) framebuffer
+ * allocation (Window.cpp:42,76), Texture::init() EWA table (Texture.h:53-62,
+ * Main.cpp:25), MaterialBuffer::init() (Material.h:52-60, Main.cpp:26) and
+ * WorkerThreads::init (WorkerThread.cpp:72-114).                              */
+int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx);
+int rtx_destroy(rtx_ctx * ctx);
+const char * rtx_last_error(const rtx_ctx * ctx);
+int rtx_abi_version(void);
+
+/* ---- scene data that lives across frames -------------------------------- */
+
+/* A flattened BottomLevelBVH (BottomLevelBVH.h:5-34 after flatten(),
+ * BottomLevelBVH.cpp:196-212): nodes, and hot/cold triangles already in leaf
+ * order.  Replaces BottomLevelBVH::load (BottomLevelBVH.cpp:18-59).          */
+int rtx_upload_blas(rtx_ctx * ctx, int32_t blas_id,
+                    const rtx_bvh_node * nodes, int32_t node_count,
+                    const rtx_triangle_hot * tri_hot, const rtx_triangle_cold * tri_cold,
+                    int32_t triangle_count, int32_t material_offset);
+
+/* The global MaterialBuffer::materials[] (Material.h:28-61); index 0 is the
+ * all-zero default material.                                                 */
+int rtx_upload_materials(rtx_ctx * ctx, const rtx_material * materials, int32_t count);
+
+/* One Texture (Texture.h:8-19): linear-space float3 texels, mip chain
+ * appended as Texture::load builds it (Texture.cpp:58-117).                  */
+int rtx_upload_texture(rtx_ctx * ctx, int32_t texture_id, const rtx_texture_desc * desc,
+                       const float * texels_rgb, int64_t texel_count);
+
+/* Sky (Sky.cpp:8-26): size*size float3 texels.                               */
+int rtx_upload_sky(rtx_ctx * ctx, const float * texels_rgb, int32_t size);
+
+/* ---- per frame ------------------------------------------------------------ */
+
+/* The result of Scene::update(delta) (Scene.cpp:139-171): camera basis,
+ * instance matrices, rebuilt TLAS, analytic primitives, lights.  Must be
+ * called before rendering, never concurrently with it (Main.cpp:54-57).      */
+int rtx_set_frame(rtx_ctx * ctx, const rtx_frame * frame);
+
+enum {
+    RTX_RENDER_COUNT_WORK = 1          /* also fill rtx_work_counters (instrumented kernels) */
+};
+
+/* Renders tiles first_tile + i*tile_stride, i in [0, tile_count), numbered as
+ * WorkerThread.cpp:57-61 (task -> x = (task % tile_count_x)*32, y = (task /
+ * tile_count_x)*32, clipped at the right/bottom edge), each exactly as
+ * Raytracer::render_tile (Raytracer.cpp:3-85) would, into the context's
+ * device framebuffer.  Replaces wake_up_worker_threads + wait_on_worker_threads
+ * (WorkerThread.cpp:116-129).  Returns after the work has been queued on the
+ * context's stream; stats/work (may be NULL) are valid after rtx_synchronize
+ * or any read-back call.                                                       */
+int rtx_render_tiles(rtx_ctx * ctx, int32_t first_tile, int32_t tile_stride, int32_t tile_count,
+                     uint32_t flags);
+int rtx_synchronize(rtx_ctx * ctx);
+int rtx_get_stats(rtx_ctx * ctx, rtx_stats * stats, rtx_work_counters * work);
+
+/* Window::plot sink (Window.h:56-65).  rgb_f32: width*height*3 floats (linear,
+ * before quantisation); packed_u32: width*height 0x00RRGGBB words.  Either
+ * may be NULL.  Pixels of tiles that were never rendered are zero.            */
+int rtx_read_framebuffer(rtx_ctx * ctx, float * rgb_f32, uint32_t * packed_u32);
+
+/* Device addresses of the same two buffers (for RCCL / zero-copy consumers). */
+int rtx_framebuffer_device_ptrs(rtx_ctx * ctx, void ** rgb_f32_dev, void ** packed_u32_dev);
+
+/* Timing of the kernels launched by the last rtx_render_tiles call, measured
+ * with HIP events on the context's stream.  names/ms hold up to `capacity`
+ * entries; *count receives the number of kernel launches recorded.            */
+int rtx_last_kernel_times(rtx_ctx * ctx, const char ** names, float * ms, int32_t capacity, int32_t * count);
+int rtx_enable_kernel_timing(rtx_ctx * ctx, int32_t enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

@@ -1,0 +1,459 @@
+// refdump — headless harness around the UNMODIFIED reference sources (clayne/CPU-Raytracer).
+//
+// TEST INFRASTRUCTURE ONLY.  Built by oracle/ref_harness/Makefile from the sources where they lie
+// under /root/reference (nothing is copied into this repo); the binary lands in oracle/_ref/.
+// It exists to (a) pin oracle/rt_oracle.c against the real reference and (b) dump scenes in this
+// repo's own scene format (python: cpu-raytracer_amd/pyrtx/scene_io.py) together with golden
+// framebuffers.  Nothing in the product path may link or run it.
+//
+// What it does: reads a small scene script, drives the reference's own public objects
+//   Texture::init / MaterialBuffer::init / Scene / Camera::resize / Scene::update /
+//   Raytracer::render_tile / Raytracer::bounce            (Main.cpp:25-57, Raytracer.h:11-18)
+// at SIMD_LANE_SIZE == 1 and writes:
+//   scene.rtxs   scene after Scene::update, in this repo's chunk format
+//   rgb.f32      W*H*3 fp32 linear colours = return value of Raytracer::bounce per pixel
+//   packed.u32   W*H packed pixels written by Raytracer::render_tile through Window::plot
+//   stats.json   PerformanceStats of both passes, timings
+//
+// The only reference behaviour restated here is the 10-line primary-ray set-up needed to call
+// bounce() directly (Raytracer.cpp:45-59); it is cross-checked against render_tile's packed output
+// for every pixel on every run (see check_packed below).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <chrono>
+#include <sstream>
+#include <fstream>
+#include <map>
+#include <unordered_map>
+#include <algorithm>
+#include <filesystem>
+
+// The harness must read a few private fields (Sphere radius, Plane axes, Texture texels, Sky
+// texels) and call the private Raytracer::bounce.  Access control is lifted for THIS translation
+// unit only; the reference's own translation units are compiled untouched.
+#define private public
+#include "Raytracer.h"
+#undef private
+
+#include "../../include/rtx.h"
+
+// ---- headless Window (Window.cpp is SDL/GL and is not compiled) -------------------------------
+Window::Window(int width, int height, const char * title) :
+	width(width), height(height),
+	tile_count_x((width  + tile_width  - 1) / tile_width),
+	tile_count_y((height + tile_height - 1) / tile_height)
+{
+	frame_buffer = new unsigned[width * height];
+	memset(frame_buffer, 0, sizeof(unsigned) * width * height);
+}
+Window::~Window() { delete [] frame_buffer; }
+
+// Scene::update polls the keyboard (Scene.cpp:165).  Headless: no key is ever down.
+static Uint8 no_keys[SDL_NUM_SCANCODES];
+extern "C" const Uint8 * SDL_GetKeyboardState(int * numkeys) { if (numkeys) *numkeys = SDL_NUM_SCANCODES; return no_keys; }
+
+// ---- chunk writer ------------------------------------------------------------------------------
+struct ChunkWriter {
+	FILE * f;
+	explicit ChunkWriter(const std::string & path) {
+		f = fopen(path.c_str(), "wb");
+		if (!f) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(2); }
+		fwrite("RTXSCN01", 1, 8, f);
+	}
+	~ChunkWriter() { fclose(f); }
+	void chunk(const char tag[5], uint32_t n, const void * data, uint64_t nbytes) {
+		fwrite(tag, 1, 4, f);
+		fwrite(&n, 4, 1, f);
+		fwrite(&nbytes, 8, 1, f);
+		if (nbytes) fwrite(data, 1, nbytes, f);
+		static const char zeros[8] = {0};
+		uint64_t pad = (8 - (nbytes & 7)) & 7;
+		if (pad) fwrite(zeros, 1, pad, f);
+	}
+};
+
+static void v3(float * dst, const Vector3 & v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
+static void v3(float * dst, const SIMD_Vector3 & v) { dst[0] = v.x[0]; dst[1] = v.y[0]; dst[2] = v.z[0]; }
+
+struct MeshSpec { std::string path; Vector3 pos; Quaternion rot; };
+
+struct MatEdit { std::string target; std::string field; std::vector<std::string> args; };
+
+static std::vector<std::string> split(const std::string & s) {
+	std::istringstream is(s); std::vector<std::string> out; std::string w;
+	while (is >> w) out.push_back(w);
+	return out;
+}
+
+static Scene * g_scene;
+
+static int resolve_material(const std::string & target) {
+	// mesh:<i>:<local>, sphere:<i>, plane:<i>, global:<id>
+	std::vector<std::string> parts; { std::string t = target; size_t p; while ((p = t.find(':')) != std::string::npos) { parts.push_back(t.substr(0, p)); t = t.substr(p + 1); } parts.push_back(t); }
+	if (parts[0] == "mesh")   return g_scene->top_level_bvh.primitives[atoi(parts[1].c_str())].bvh->material_offset + atoi(parts[2].c_str());
+	if (parts[0] == "sphere") return g_scene->spheres[atoi(parts[1].c_str())].material_id;
+	if (parts[0] == "plane")  return g_scene->planes [atoi(parts[1].c_str())].material_id;
+	if (parts[0] == "global") return atoi(parts[1].c_str());
+	fprintf(stderr, "bad material target %s\n", target.c_str()); exit(2);
+}
+
+int main(int argc, char ** argv) {
+	if (argc < 3) { fprintf(stderr, "usage: refdump <script> <outdir> [--threads N]\n  (cwd must contain ./Data as the reference expects, Util.h:6)\n"); return 2; }
+	std::string script = argv[1], outdir = argv[2];
+	std::filesystem::create_directories(outdir);
+
+	int W = 256, H = 256, bounces = NUMBER_OF_BOUNCES, frames = 1; float delta = 0.0f;
+	bool keep_base = false, drop_base_meshes = false, have_camera = false, have_ambient = false;
+	Vector3 cam_pos; Quaternion cam_rot; Vector3 ambient;
+	std::vector<MeshSpec> meshes;
+	struct SphereSpec { Vector3 c; float r; }; std::vector<SphereSpec> spheres;
+	struct PlaneSpec { Vector3 p; Quaternion q; }; std::vector<PlaneSpec> planes;
+	struct PL { Vector3 c, p; }; std::vector<PL> pls;
+	struct SL { Vector3 c, p, d; float in, out; }; std::vector<SL> sls;
+	struct DL { Vector3 c, d; }; std::vector<DL> dls;
+	bool lights_given = false;
+	std::vector<MatEdit> edits;
+	struct TexProbe { std::string path; int n; unsigned seed; }; std::vector<TexProbe> probes;
+	int render_reps = 1;
+
+	{
+		std::ifstream in(script);
+		if (!in) { fprintf(stderr, "cannot read %s\n", script.c_str()); return 2; }
+		std::string line;
+		while (std::getline(in, line)) {
+			size_t h = line.find('#'); if (h != std::string::npos) line = line.substr(0, h);
+			std::vector<std::string> w = split(line); if (w.empty()) continue;
+			auto F = [&](int i) { return (float)atof(w[i].c_str()); };
+			if      (w[0] == "size")    { W = atoi(w[1].c_str()); H = atoi(w[2].c_str()); }
+			else if (w[0] == "bounces") { bounces = atoi(w[1].c_str()); }
+			else if (w[0] == "frames")  { frames = atoi(w[1].c_str()); delta = F(2); }
+			else if (w[0] == "reps")    { render_reps = atoi(w[1].c_str()); }
+			else if (w[0] == "base")    { keep_base = (w[1] == "keep"); }
+			else if (w[0] == "drop_base_meshes") { drop_base_meshes = true; }
+			else if (w[0] == "camera")  { have_camera = true; cam_pos = Vector3(F(1), F(2), F(3)); cam_rot = Quaternion(F(4), F(5), F(6), F(7)); }
+			else if (w[0] == "camera_axis_angle") { have_camera = true; cam_pos = Vector3(F(1), F(2), F(3)); cam_rot = Quaternion::axis_angle(Vector3(F(4), F(5), F(6)), F(7)); }
+			else if (w[0] == "ambient") { have_ambient = true; ambient = Vector3(F(1), F(2), F(3)); }
+			else if (w[0] == "mesh")    { MeshSpec m; m.path = w[1]; m.pos = Vector3(F(2), F(3), F(4)); m.rot = w.size() >= 9 ? Quaternion(F(5), F(6), F(7), F(8)) : Quaternion(); meshes.push_back(m); }
+			else if (w[0] == "mesh_axis_angle") { MeshSpec m; m.path = w[1]; m.pos = Vector3(F(2), F(3), F(4)); m.rot = Quaternion::axis_angle(Vector3(F(5), F(6), F(7)), F(8)); meshes.push_back(m); }
+			else if (w[0] == "sphere")  { spheres.push_back({ Vector3(F(1), F(2), F(3)), F(4) }); }
+			else if (w[0] == "plane")   { planes.push_back({ Vector3(F(1), F(2), F(3)), w.size() >= 8 ? Quaternion(F(4), F(5), F(6), F(7)) : Quaternion() }); }
+			else if (w[0] == "plane_axis_angle") { planes.push_back({ Vector3(F(1), F(2), F(3)), Quaternion::axis_angle(Vector3(F(4), F(5), F(6)), F(7)) }); }
+			else if (w[0] == "point")   { lights_given = true; pls.push_back({ Vector3(F(1), F(2), F(3)), Vector3(F(4), F(5), F(6)) }); }
+			else if (w[0] == "spot")    { lights_given = true; sls.push_back({ Vector3(F(1), F(2), F(3)), Vector3(F(4), F(5), F(6)), Vector3(F(7), F(8), F(9)), F(10), F(11) }); }
+			else if (w[0] == "dir")     { lights_given = true; dls.push_back({ Vector3(F(1), F(2), F(3)), Vector3(F(4), F(5), F(6)) }); }
+			else if (w[0] == "nolights") { lights_given = true; }
+			else if (w[0] == "matset")  { MatEdit e; e.target = w[1]; e.field = w[2]; e.args.assign(w.begin() + 3, w.end()); edits.push_back(e); }
+			else if (w[0] == "texprobe") { probes.push_back({ w[1], atoi(w[2].c_str()), (unsigned)strtoul(w[3].c_str(), nullptr, 0) }); }
+			else { fprintf(stderr, "unknown script command '%s'\n", w[0].c_str()); return 2; }
+		}
+	}
+
+	// ---- Main.cpp:18-40 ---------------------------------------------------------------------------
+	Window window(W, H, "refdump");
+	Texture::init();
+	MaterialBuffer::init();
+
+	Scene scene; g_scene = &scene;
+	scene.camera.resize(W, H);
+
+	if (!keep_base) {
+		scene.spheres.primitive_count = 0;
+		scene.planes.primitive_count  = 0;
+	}
+	if (!spheres.empty()) {
+		int base = keep_base ? scene.spheres.primitive_count : 0;
+		Sphere * s = new Sphere[base + spheres.size()];
+		for (int i = 0; i < base; i++) s[i] = scene.spheres.primitives[i];
+		for (size_t i = 0; i < spheres.size(); i++) { s[base + i].init(spheres[i].r); s[base + i].transform.position = spheres[i].c; }
+		scene.spheres.primitives = s; scene.spheres.primitive_count = base + (int)spheres.size();
+	}
+	if (!planes.empty()) {
+		int base = keep_base ? scene.planes.primitive_count : 0;
+		Plane * p = new Plane[base + planes.size()];
+		for (int i = 0; i < base; i++) p[i] = scene.planes.primitives[i];
+		for (size_t i = 0; i < planes.size(); i++) { p[base + i].transform.position = planes[i].p; p[base + i].transform.rotation = planes[i].q; }
+		scene.planes.primitives = p; scene.planes.primitive_count = base + (int)planes.size();
+	}
+	if (!keep_base || !meshes.empty()) {
+		int base = (keep_base && !drop_base_meshes) ? scene.top_level_bvh.primitive_count : 0;
+		std::vector<Mesh> old(scene.top_level_bvh.primitives, scene.top_level_bvh.primitives + base);
+		int n = base + (int)meshes.size();
+		if (n == 0) { fprintf(stderr, "script defines no mesh (TopLevelBVH::init asserts count > 0)\n"); return 2; }
+		scene.top_level_bvh.init(n);
+		for (int i = 0; i < base; i++) scene.top_level_bvh.primitives[i] = old[i];
+		for (size_t i = 0; i < meshes.size(); i++) {
+			Mesh & m = scene.top_level_bvh.primitives[base + i];
+			m.transform.position = meshes[i].pos;
+			m.transform.rotation = meshes[i].rot;
+			m.init(meshes[i].path.c_str());
+		}
+	}
+	if (lights_given) {
+		scene.point_light_count = (int)pls.size();
+		scene.point_lights = (PointLight *)malloc(sizeof(PointLight) * (pls.size() + 1));
+		for (size_t i = 0; i < pls.size(); i++) new (&scene.point_lights[i]) PointLight(pls[i].c, pls[i].p);
+		scene.spot_light_count = (int)sls.size();
+		scene.spot_lights = (SpotLight *)malloc(sizeof(SpotLight) * (sls.size() + 1));
+		for (size_t i = 0; i < sls.size(); i++) new (&scene.spot_lights[i]) SpotLight(sls[i].c, sls[i].p, Vector3::normalize(sls[i].d), sls[i].in, sls[i].out);
+		scene.directional_light_count = (int)dls.size();
+		scene.directional_lights = (DirectionalLight *)malloc(sizeof(DirectionalLight) * (dls.size() + 1));
+		for (size_t i = 0; i < dls.size(); i++) new (&scene.directional_lights[i]) DirectionalLight(dls[i].c, Vector3::normalize(dls[i].d));
+	}
+	if (have_camera)  { scene.camera.position = cam_pos; scene.camera.rotation = cam_rot; }
+	if (have_ambient) { scene.ambient_lighting = ambient; }
+
+	for (const MatEdit & e : edits) {
+		Material & m = MaterialBuffer::materials[resolve_material(e.target)];
+		auto F = [&](int i) { return (float)atof(e.args[i].c_str()); };
+		if      (e.field == "diffuse")       m.diffuse       = Vector3(F(0), F(1), F(2));
+		else if (e.field == "reflection")    m.reflection    = Vector3(F(0), F(1), F(2));
+		else if (e.field == "transmittance") m.transmittance = Vector3(F(0), F(1), F(2));
+		else if (e.field == "ior")           m.index_of_refraction = F(0);
+		else if (e.field == "notexture")     m.texture = nullptr;
+		else if (e.field == "texture")       m.texture = Texture::load(e.args[0].c_str());
+		else { fprintf(stderr, "bad matset field %s\n", e.field.c_str()); return 2; }
+	}
+
+	// ---- Main.cpp:54: Scene::update, `frames` times ---------------------------------------------------
+	for (int f = 0; f < frames; f++) scene.update(delta);
+
+	Raytracer raytracer;
+	raytracer.scene = &scene;
+
+	// ---- pass 1: the reference's own tile loop (WorkerThread.cpp:53-65, single thread) ------------
+	PerformanceStats stats_tiles = { 0, 0, 0, 0 };
+	double best_ms = 1e30;
+	static_assert(NUMBER_OF_BOUNCES >= 0, "");
+	bool tiles_valid = (bounces == NUMBER_OF_BOUNCES);   // render_tile uses the compile-time constant
+	if (tiles_valid) {
+		for (int rep = 0; rep < render_reps; rep++) {
+			stats_tiles = { 0, 0, 0, 0 };
+			auto t0 = std::chrono::high_resolution_clock::now();
+			for (int task = window.tile_count_x * window.tile_count_y - 1; task >= 0; task--) {
+				int x = (task % window.tile_count_x) * window.tile_width;
+				int y = (task / window.tile_count_x) * window.tile_height;
+				int tw = x + window.tile_width  < window.width  ? window.tile_width  : window.width  - x;
+				int th = y + window.tile_height < window.height ? window.tile_height : window.height - y;
+				raytracer.render_tile(window, x, y, tw, th, stats_tiles);
+			}
+			auto t1 = std::chrono::high_resolution_clock::now();
+			best_ms = std::min(best_ms, std::chrono::duration<double, std::milli>(t1 - t0).count());
+		}
+	}
+
+	// ---- pass 2: bounce() per pixel for fp32 colours ----------------------------------------------
+	std::vector<float> rgb((size_t)W * H * 3);
+	std::vector<float> dist((size_t)W * H);
+	PerformanceStats stats_px = { 0, 0, 0, 0 };
+	{
+		Ray ray;
+		ray.origin = SIMD_Vector3(scene.camera.position);
+#if RAY_DIFFERENTIALS_ENABLED
+		ray.dO_dx = SIMD_Vector3(0.0f);
+		ray.dO_dy = SIMD_Vector3(0.0f);
+#endif
+		const Camera & c = scene.camera;
+		for (int j = 0; j < H; j++) for (int i = 0; i < W; i++) {
+			SIMD_float is((float)i), js((float)j);
+			SIMD_Vector3 d = SIMD_Vector3::madd(c.rotated_x_axis, is, SIMD_Vector3::madd(c.rotated_y_axis, js, c.rotated_top_left_corner));
+			SIMD_float dd = SIMD_Vector3::dot(d, d);
+			SIMD_float inv = SIMD_float::inv_sqrt(dd);
+			SIMD_float denom = inv / dd;
+#if RAY_DIFFERENTIALS_ENABLED
+			ray.dD_dx = (dd * c.rotated_x_axis - SIMD_Vector3::dot(d, c.rotated_x_axis) * d) * denom;
+			ray.dD_dy = (dd * c.rotated_y_axis - SIMD_Vector3::dot(d, c.rotated_y_axis) * d) * denom;
+#endif
+			ray.direction = d * inv;
+			stats_px.num_primary_rays++;
+			SIMD_float distance;
+			SIMD_Vector3 colour = raytracer.bounce(ray, bounces, distance, stats_px);
+			size_t p = (size_t)j * W + i;
+			rgb[3 * p + 0] = colour.x[0]; rgb[3 * p + 1] = colour.y[0]; rgb[3 * p + 2] = colour.z[0];
+			dist[p] = distance[0];
+		}
+	}
+
+	// check_packed: quantising pass 2 exactly as Window::plot does must reproduce pass 1 bit for bit
+	long packed_mismatch = -1;
+	if (tiles_valid) {
+		packed_mismatch = 0;
+		Window check(W, H, "check");
+		for (int j = 0; j < H; j++) for (int i = 0; i < W; i++) {
+			size_t p = (size_t)j * W + i;
+			check.plot(i, j, Vector3(rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2]));
+			if (check.frame_buffer[p] != window.frame_buffer[p]) packed_mismatch++;
+		}
+		if (stats_tiles.num_primary_rays != stats_px.num_primary_rays || stats_tiles.num_shadow_rays != stats_px.num_shadow_rays ||
+		    stats_tiles.num_reflection_rays != stats_px.num_reflection_rays || stats_tiles.num_refraction_rays != stats_px.num_refraction_rays) packed_mismatch += 1000000000L;
+	} else {
+		// no render_tile pass for this bounce count: quantise pass 2 through Window::plot
+		for (int j = 0; j < H; j++) for (int i = 0; i < W; i++) {
+			size_t p = (size_t)j * W + i;
+			window.plot(i, j, Vector3(rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2]));
+		}
+	}
+
+	// ---- dump scene -----------------------------------------------------------------------------------
+	{
+		ChunkWriter cw(outdir + "/scene.rtxs");
+		rtx_config conf; memset(&conf, 0, sizeof(conf));
+		conf.width = W; conf.height = H; conf.bounces = bounces; conf.stack_size = BVH_TRAVERSAL_STACK_SIZE;
+		conf.traversal_strategy = BVH_TRAVERSAL_STRATEGY; conf.texture_mode = TEXTURE_SAMPLE_MODE; conf.mip_filter = MIPMAP_FILTER;
+		conf.max_anisotropy = MAX_ANISOTROPY; conf.device = 0;
+		cw.chunk("CONF", 1, &conf, sizeof(conf));
+
+		rtx_camera cam;
+		v3(cam.position, scene.camera.position);
+		v3(cam.rotated_top_left_corner, scene.camera.rotated_top_left_corner);
+		v3(cam.rotated_x_axis, scene.camera.rotated_x_axis);
+		v3(cam.rotated_y_axis, scene.camera.rotated_y_axis);
+		cw.chunk("CAMR", 1, &cam, sizeof(cam));
+		float amb[4] = { scene.ambient_lighting.x, scene.ambient_lighting.y, scene.ambient_lighting.z, 0.0f };
+		cw.chunk("AMBT", 1, amb, sizeof(amb));
+
+		std::vector<rtx_point_light> pl(scene.point_light_count);
+		for (int i = 0; i < scene.point_light_count; i++) { v3(pl[i].colour, scene.point_lights[i].colour); v3(pl[i].position, scene.point_lights[i].position); }
+		cw.chunk("LPNT", (uint32_t)pl.size(), pl.data(), pl.size() * sizeof(rtx_point_light));
+		std::vector<rtx_spot_light> sl(scene.spot_light_count);
+		for (int i = 0; i < scene.spot_light_count; i++) {
+			const SpotLight & s = scene.spot_lights[i];
+			v3(sl[i].colour, s.colour); v3(sl[i].position, s.position); v3(sl[i].negative_direction, s.negative_direction);
+			sl[i].inner_cutoff = s.inner_cutoff; sl[i].outer_cutoff = s.outer_cutoff;
+		}
+		cw.chunk("LSPT", (uint32_t)sl.size(), sl.data(), sl.size() * sizeof(rtx_spot_light));
+		std::vector<rtx_directional_light> dl(scene.directional_light_count);
+		for (int i = 0; i < scene.directional_light_count; i++) { v3(dl[i].colour, scene.directional_lights[i].colour); v3(dl[i].negative_direction, scene.directional_lights[i].negative_direction); }
+		cw.chunk("LDIR", (uint32_t)dl.size(), dl.data(), dl.size() * sizeof(rtx_directional_light));
+
+		// textures referenced by materials, in order of first use
+		std::vector<const Texture *> textures;
+		auto tex_id = [&](const Texture * t) -> int {
+			if (!t) return -1;
+			for (size_t i = 0; i < textures.size(); i++) if (textures[i] == t) return (int)i;
+			textures.push_back(t); return (int)textures.size() - 1;
+		};
+		std::vector<rtx_material> mats(MaterialBuffer::material_count);
+		for (int i = 0; i < MaterialBuffer::material_count; i++) {
+			const Material & m = MaterialBuffer::materials[i];
+			memset(&mats[i], 0, sizeof(rtx_material));
+			v3(mats[i].diffuse, m.diffuse); mats[i].texture_id = tex_id(m.texture);
+			v3(mats[i].reflection, m.reflection); v3(mats[i].transmittance, m.transmittance);
+			mats[i].index_of_refraction = m.index_of_refraction;
+		}
+		cw.chunk("MATL", (uint32_t)mats.size(), mats.data(), mats.size() * sizeof(rtx_material));
+		for (size_t t = 0; t < textures.size(); t++) {
+			const Texture * tx = textures[t];
+			rtx_texture_desc d; memset(&d, 0, sizeof(d));
+			d.width = tx->width; d.height = tx->height; d.mipmapped = tx->mipmapped ? 1 : 0; d.mip_levels = tx->mip_levels;
+			for (int l = 0; l < tx->mip_levels && l < RTX_MAX_MIP_LEVELS; l++) d.mip_offsets[l] = tx->mip_offsets[l];
+			int64_t texels = (int64_t)tx->width * tx->height;
+			if (tx->mipmapped) {
+				// extent of the mip chain actually written by Texture::load (Texture.cpp:76-117)
+				int lw = tx->width >> (tx->mip_levels - 1), lh = tx->height >> (tx->mip_levels - 1);
+				texels = tx->mip_offsets[tx->mip_levels - 1] + (int64_t)std::max(lw, 1) * std::max(lh, 1);
+			}
+			cw.chunk("TEXH", (uint32_t)t, &d, sizeof(d));
+			cw.chunk("TEXL", (uint32_t)t, tx->data, (uint64_t)texels * 12);
+		}
+		cw.chunk("SKYD", (uint32_t)scene.sky.size, scene.sky.data, (uint64_t)scene.sky.size * scene.sky.size * 12);
+
+		// BLAS table: unique BottomLevelBVH pointers in order of first use
+		std::vector<const BottomLevelBVH *> blas;
+		auto blas_id = [&](const BottomLevelBVH * b) -> int {
+			for (size_t i = 0; i < blas.size(); i++) if (blas[i] == b) return (int)i;
+			blas.push_back(b); return (int)blas.size() - 1;
+		};
+		const TopLevelBVH & tl = scene.top_level_bvh;
+		std::vector<rtx_instance> inst(tl.primitive_count);
+		for (int i = 0; i < tl.primitive_count; i++) {
+			memset(&inst[i], 0, sizeof(rtx_instance));
+			inst[i].blas_id = blas_id(tl.primitives[i].bvh);
+			memcpy(inst[i].world,     tl.primitives[i].transform.world_matrix.cells, 64);
+			memcpy(inst[i].world_inv, tl.primitives[i].transform_inv.cells,          64);
+		}
+		for (size_t b = 0; b < blas.size(); b++) {
+			int32_t hdr[4] = { blas[b]->node_count, blas[b]->index_count, blas[b]->material_offset, blas[b]->triangle_count };
+			cw.chunk("BLSH", (uint32_t)b, hdr, sizeof(hdr));
+			{
+				std::vector<BVHNode> bn(blas[b]->nodes, blas[b]->nodes + blas[b]->node_count);
+				if (bn.size() > 1) memset(&bn[1], 0, sizeof(BVHNode));
+				cw.chunk("BLSN", (uint32_t)b, bn.data(), (uint64_t)blas[b]->node_count * sizeof(BVHNode));
+			}
+			cw.chunk("BLST", (uint32_t)b, blas[b]->triangles_hot,  (uint64_t)blas[b]->index_count * sizeof(BottomLevelBVH::TriangleHot));
+			cw.chunk("BLSC", (uint32_t)b, blas[b]->triangles_cold, (uint64_t)blas[b]->index_count * sizeof(BottomLevelBVH::TriangleCold));
+		}
+		cw.chunk("INST", (uint32_t)inst.size(), inst.data(), inst.size() * sizeof(rtx_instance));
+		{
+			// node 1 is never written or read by the reference (BVHBuilders.h:20-21 starts at 2): zero it so fixtures are deterministic
+			std::vector<BVHNode> tn(tl.nodes, tl.nodes + tl.node_count);
+			if (tn.size() > 1) memset(&tn[1], 0, sizeof(BVHNode));
+			cw.chunk("TLSN", (uint32_t)tl.node_count, tn.data(), (uint64_t)tl.node_count * sizeof(BVHNode));
+		}
+		cw.chunk("TLSI", (uint32_t)tl.leaf_count, tl.indices, (uint64_t)tl.leaf_count * 4);
+		// instance positions: input of the TLAS rebuild (TopLevelBVH.cpp:32-45 sorts by transform.position)
+		std::vector<float> ipos(tl.primitive_count * 7), iaabb(tl.primitive_count * 6);
+		for (int i = 0; i < tl.primitive_count; i++) {
+			const Transform & t = tl.primitives[i].transform;
+			float * p = &ipos[7 * i]; p[0] = t.position.x; p[1] = t.position.y; p[2] = t.position.z; p[3] = t.rotation.x; p[4] = t.rotation.y; p[5] = t.rotation.z; p[6] = t.rotation.w;
+			v3(&iaabb[6 * i], tl.primitives[i].aabb.min); v3(&iaabb[6 * i + 3], tl.primitives[i].aabb.max);
+		}
+		cw.chunk("IPOS", (uint32_t)tl.primitive_count, ipos.data(), ipos.size() * 4);
+		cw.chunk("IAAB", (uint32_t)tl.primitive_count, iaabb.data(), iaabb.size() * 4);
+
+		std::vector<rtx_sphere> sp(scene.spheres.primitive_count);
+		for (int i = 0; i < scene.spheres.primitive_count; i++) {
+			const Sphere & s = scene.spheres.primitives[i];
+			v3(sp[i].center, s.transform.position); sp[i].radius_inv = s.radius_inv; sp[i].radius_squared = s.radius_squared; sp[i].material_id = s.material_id;
+		}
+		cw.chunk("SPHR", (uint32_t)sp.size(), sp.data(), sp.size() * sizeof(rtx_sphere));
+		std::vector<rtx_plane> pn(scene.planes.primitive_count);
+		for (int i = 0; i < scene.planes.primitive_count; i++) {
+			const Plane & p = scene.planes.primitives[i];
+			memset(&pn[i], 0, sizeof(rtx_plane));
+			v3(pn[i].normal, p.world_normal); pn[i].distance = p.world_distance; v3(pn[i].u_axis, p.u_axis); v3(pn[i].v_axis, p.v_axis); pn[i].material_id = p.material_id;
+		}
+		cw.chunk("PLAN", (uint32_t)pn.size(), pn.data(), pn.size() * sizeof(rtx_plane));
+	}
+
+	auto dump = [&](const std::string & name, const void * data, size_t bytes) {
+		FILE * f = fopen((outdir + "/" + name).c_str(), "wb"); fwrite(data, 1, bytes, f); fclose(f);
+	};
+	dump("rgb.f32", rgb.data(), rgb.size() * 4);
+	dump("dist.f32", dist.data(), dist.size() * 4);
+	dump("packed.u32", window.frame_buffer, (size_t)W * H * 4);
+
+	// ---- texture probes: Texture::sample at seeded inputs (Texture.h:33-49) ------------------------
+	for (size_t k = 0; k < probes.size(); k++) {
+		const Texture * tx = Texture::load(probes[k].path.c_str());
+		std::vector<float> io((size_t)probes[k].n * 9);
+		unsigned s = probes[k].seed;
+		auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) * (1.0f / 16777216.0f); };
+		for (int i = 0; i < probes[k].n; i++) {
+			float * r = &io[9 * (size_t)i];
+			r[0] = rnd() * 4.0f - 2.0f; r[1] = rnd() * 4.0f - 2.0f;
+			float scale = powf(2.0f, -10.0f * rnd());          // footprints from ~1 texel to the whole texture
+			r[2] = (rnd() - 0.5f) * scale; r[3] = (rnd() - 0.5f) * scale * (rnd() < 0.3f ? 0.05f : 1.0f);
+			r[4] = (rnd() - 0.5f) * scale; r[5] = (rnd() - 0.5f) * scale * (rnd() < 0.3f ? 0.05f : 1.0f);
+			Vector3 c = tx->sample(r[0], r[1], r[2], r[3], r[4], r[5]);
+			r[6] = c.x; r[7] = c.y; r[8] = c.z;
+		}
+		char name[64]; snprintf(name, sizeof(name), "texprobe%zu.f32", k);
+		dump(name, io.data(), io.size() * 4);
+	}
+
+	{
+		FILE * f = fopen((outdir + "/stats.json").c_str(), "w");
+		fprintf(f, "{\"width\": %d, \"height\": %d, \"bounces\": %d, \"frames\": %d, \"delta\": %.9g,\n", W, H, bounces, frames, delta);
+		fprintf(f, " \"mip_filter\": %d, \"texture_mode\": %d, \"scene_variant\": %d, \"simd_lane_size\": %d,\n", MIPMAP_FILTER, TEXTURE_SAMPLE_MODE, SCENE, SIMD_LANE_SIZE);
+		fprintf(f, " \"primary\": %d, \"shadow\": %d, \"reflection\": %d, \"refraction\": %d,\n", stats_px.num_primary_rays, stats_px.num_shadow_rays, stats_px.num_reflection_rays, stats_px.num_refraction_rays);
+		fprintf(f, " \"render_tile_pass\": %s, \"packed_mismatch\": %ld, \"render_tile_ms_1thread\": %.3f}\n", tiles_valid ? "true" : "false", packed_mismatch, tiles_valid ? best_ms : -1.0);
+		fclose(f);
+	}
+	printf("refdump: %dx%d bounces=%d rays p=%d s=%d rl=%d rr=%d packed_mismatch=%ld tile_ms=%.2f\n", W, H, bounces,
+	       stats_px.num_primary_rays, stats_px.num_shadow_rays, stats_px.num_reflection_rays, stats_px.num_refraction_rays, packed_mismatch, tiles_valid ? best_ms : -1.0);
+	return packed_mismatch > 0 ? 3 : 0;
+}

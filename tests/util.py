@@ -1,0 +1,59 @@
+"""Shared helpers for the tests (golden loading, comparisons)."""
+import gzip
+import os
+
+import numpy as np
+
+from pyrtx import scene_io as sio
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+# name -> (scene dir, golden file tag, config overrides)
+GOLDENS = {
+    "cube": ("cube", None, {}),
+    "monkey": ("monkey", None, {}),
+    "monkey_small": ("monkey_small", None, {}),
+    "materials_aniso": ("materials", "aniso", {"mip_filter": 1, "texture_mode": 2}),
+    "materials_trilinear": ("materials", "trilinear", {"mip_filter": 0, "texture_mode": 2}),
+    "materials_ewa": ("materials", "ewa", {"mip_filter": 2, "texture_mode": 2}),
+    "materials_bilinear": ("materials", "bilinear", {"mip_filter": 1, "texture_mode": 1}),
+    "dynamic": ("dynamic", None, {}),
+    "tori16": ("tori16", None, {}),
+    "tori16_f1": ("tori16_f1", None, {}),
+}
+
+
+def load_golden(name):
+    d, tag, over = GOLDENS[name]
+    with gzip.open(os.path.join(GOLDEN, d, "scene.rtxs.gz"), "rb") as f:
+        sc = sio.load_scene(f.read())
+    for k, v in over.items():
+        sc.config[k] = v
+    if over.get("texture_mode", 2) != 2:
+        # non-mipmap builds of the reference never build mip chains (Texture.cpp:49-55)
+        for t in sc.textures:
+            t.desc["mipmapped"] = 0
+            t.desc["mip_levels"] = 1
+    g = dict(np.load(os.path.join(GOLDEN, d, f"golden{'_' + tag if tag else ''}.npz")))
+    return sc, g
+
+
+def compare_to_golden(out, g):
+    """out: dict(rgb (H,W,3), packed (H,W), stats dict).  Returns dict of comparison figures."""
+    if "xs" in g:
+        rgb = out["rgb"][g["ys"], g["xs"]]
+        packed = out["packed"][g["ys"], g["xs"]]
+    else:
+        rgb, packed = out["rgb"], out["packed"]
+    diff = np.abs(rgb.astype(np.float64) - g["rgb"].astype(np.float64))
+    both_nan = np.isnan(rgb) & np.isnan(g["rgb"])
+    diff[both_nan] = 0.0
+    return {
+        "max_abs": float(np.nanmax(diff)) if diff.size else 0.0,
+        "nan_mismatch": int((np.isnan(rgb) != np.isnan(g["rgb"])).sum()),
+        "bit_exact": bool(np.array_equal(rgb.view(np.uint32), g["rgb"].view(np.uint32))),
+        "n_diff_pixels": int((diff.max(axis=-1) > 0).sum()),
+        "packed_mismatch": int((packed != g["packed"]).sum()),
+        "stats_equal": [int(out["stats"][k]) for k in ("primary", "shadow", "reflection", "refraction")] == g["stats"].tolist(),
+    }
