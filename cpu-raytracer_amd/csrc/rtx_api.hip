@@ -1,0 +1,568 @@
+// rtx_api.hip — host side of librtx_hip.so: the C ABI of include/rtx.h over the gfx950 kernels.
+//
+// One context = one GPU, one HIP stream.  Scene data is uploaded once and stays resident in HBM;
+// rtx_set_frame uploads what Scene::update produces (< 8 KiB for 16 instances); rtx_render_tiles
+// enqueues the whole wavefront pipeline for a batch of tiles without any host synchronisation:
+//
+//   for level = 0 .. bounces:  k_trace<closest>  ->  k_shade  ->  k_trace<any>
+//   for level = bounces .. 0:  k_resolve
+//
+// Queue sizes are only known on the device (DevCounters), so every kernel reads its element count
+// from HBM and the launch geometry is fixed (persistent grids).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "rtx_device.h"
+#include "rtx_math.h"
+#include "rtx_libm.h"
+#include "rtx_texture.h"
+#include "rtx_trace.h"
+#include "rtx_shade.h"
+
+#define SLOT_BUDGET (48ll * 1000 * 1000)      // ray slots per batch of tiles (see plan_batch)
+
+struct DevBuf {
+    void * p = nullptr; size_t cap = 0;
+};
+
+struct KernelTime { const char * name; hipEvent_t a, b; };
+
+struct rtx_ctx {
+    rtx_config cfg;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n_cu = 0;
+
+    std::vector<DevBlas> h_blas;
+    std::vector<std::vector<void *>> blas_allocs;
+    DevBuf d_blas, d_materials, d_textures, d_sky, d_ewa;
+    std::vector<DevTexture> h_tex;
+    std::vector<void *> tex_allocs;
+    int material_count = 0, sky_size = 0;
+
+    DevBuf f_tlas, f_tlas_idx, f_inst, f_sph, f_pln, f_pl, f_sl, f_dl;
+    DevScene scene;
+    bool frame_set = false;
+
+    DevQueues q;
+    DevBuf qb[20];
+    size_t slots_alloc = 0, shadow_alloc = 0;
+    DevBuf d_counters, d_spill, d_fb_rgb, d_fb_packed;
+    int trace_blocks_closest = 0, trace_blocks_any = 0;
+
+    rtx_stats stats_acc; rtx_work_counters work_acc; uint32_t err_flags_acc = 0;
+    bool stats_pending = false;
+    std::vector<DevCounters *> pending_host;   // pinned copies, one per batch
+
+    bool timing = false;
+    std::vector<KernelTime> times;
+    std::vector<hipEvent_t> event_pool;
+    size_t event_next = 0;
+};
+
+#define HIP_OK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return RTX_ERR_HIP; } } while (0)
+
+static int ensure(rtx_ctx * c, DevBuf & b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return RTX_OK;
+    if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { c->err = std::string("hipMalloc: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? RTX_ERR_OOM : RTX_ERR_HIP; }
+    b.cap = bytes;
+    return RTX_OK;
+}
+
+static int upload(rtx_ctx * c, DevBuf & b, const void * src, size_t bytes) {
+    int rc = ensure(c, b, bytes);
+    if (rc) return rc;
+    if (bytes) HIP_OK(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return RTX_OK;
+}
+
+static void convert_nodes(const rtx_bvh_node * nodes, int n, std::vector<float4> & out) {
+    out.resize((size_t)2 * (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        float l, cnt;
+        memcpy(&l, &nodes[i].left_or_first, 4); memcpy(&cnt, &nodes[i].count, 4);
+        out[2 * i]     = make_float4(nodes[i].aabb_min[0], nodes[i].aabb_min[1], nodes[i].aabb_min[2], l);
+        out[2 * i + 1] = make_float4(nodes[i].aabb_max[0], nodes[i].aabb_max[1], nodes[i].aabb_max[2], cnt);
+    }
+}
+
+extern "C" int rtx_abi_version(void) { return RTX_ABI_VERSION; }
+
+extern "C" const char * rtx_last_error(const rtx_ctx * ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
+    if (!config || !out_ctx) return RTX_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    if (config->width <= 0 || config->height <= 0 || config->bounces < 0) return RTX_ERR_INVALID_ARG;
+    if (config->bounces + 1 > RTX_MAX_LEVELS) return RTX_ERR_LIMIT;
+    if (config->stack_size < 1 || config->stack_size > RTX_MAX_STACK) return RTX_ERR_LIMIT;
+    if (config->traversal_strategy < 0 || config->traversal_strategy > 1 || config->texture_mode < 0 || config->texture_mode > 2 ||
+        config->mip_filter < 0 || config->mip_filter > 2) return RTX_ERR_INVALID_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RTX_ERR_NO_DEVICE;
+    if (config->device < 0 || config->device >= n_dev) return RTX_ERR_NO_DEVICE;
+    if (hipSetDevice(config->device) != hipSuccess) return RTX_ERR_NO_DEVICE;
+
+    rtx_ctx * c = new rtx_ctx();
+    c->cfg = *config;
+    memset(&c->scene, 0, sizeof(c->scene));
+    memset(&c->q, 0, sizeof(c->q));
+    memset(&c->stats_acc, 0, sizeof(c->stats_acc));
+    memset(&c->work_acc, 0, sizeof(c->work_acc));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, config->device) != hipSuccess) { delete c; return RTX_ERR_HIP; }
+    c->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RTX_ERR_HIP; }
+
+    // Texture::init(alpha = 2) EWA weight table, Texture.h:53-62 (host libm, like the reference; shipped as data)
+    float ewa[RTX_EWA_LUT_SIZE];
+    {
+        const float alpha = 2.0f;
+        const float denom = 1.0f / (float)(RTX_EWA_LUT_SIZE - 1);
+        const float exp_neg_alpha = expf(-alpha);
+        for (int i = 0; i < RTX_EWA_LUT_SIZE; i++) { float r2 = (float)i * denom; ewa[i] = expf(-alpha * r2) - exp_neg_alpha; }
+    }
+    int rc = upload(c, c->d_ewa, ewa, sizeof(ewa));
+    // MaterialBuffer::init(): material 0 = black default, Material.h:52-60
+    rtx_material m0; memset(&m0, 0, sizeof(m0)); m0.texture_id = -1; m0.index_of_refraction = 1.0f;
+    if (!rc) rc = upload(c, c->d_materials, &m0, sizeof(m0));
+    c->material_count = 1;
+    // Window framebuffer, Window.cpp:42,76
+    const size_t px = (size_t)config->width * config->height;
+    if (!rc) rc = ensure(c, c->d_fb_rgb, px * 12);
+    if (!rc) rc = ensure(c, c->d_fb_packed, px * 4);
+    if (!rc) rc = ensure(c, c->d_counters, sizeof(DevCounters));
+    float zero_sky[6] = { 0, 0, 0, 0, 0, 0 };
+    if (!rc) rc = upload(c, c->d_sky, zero_sky, sizeof(zero_sky));
+    c->sky_size = 1;
+    if (rc) { rtx_destroy(c); return rc; }
+    hipMemset(c->d_fb_rgb.p, 0, px * 12);
+    hipMemset(c->d_fb_packed.p, 0, px * 4);
+
+    int bpc = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace<false, false>, RTX_TRACE_BLOCK, 0);
+    c->trace_blocks_closest = c->n_cu * (bpc > 0 ? bpc : 2);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace<true, false>, RTX_TRACE_BLOCK, 0);
+    c->trace_blocks_any = c->n_cu * (bpc > 0 ? bpc : 2);
+    const int max_blocks = c->trace_blocks_closest > c->trace_blocks_any ? c->trace_blocks_closest : c->trace_blocks_any;
+    c->q.spill_threads = max_blocks * RTX_TRACE_BLOCK;
+    rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4);
+    if (rc) { rtx_destroy(c); return rc; }
+    *out_ctx = c;
+    return RTX_OK;
+}
+
+extern "C" int rtx_destroy(rtx_ctx * c) {
+    if (!c) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto & v : c->blas_allocs) for (void * p : v) hipFree(p);
+    for (void * p : c->tex_allocs) hipFree(p);
+    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->f_tlas, &c->f_tlas_idx, &c->f_inst, &c->f_sph,
+                        &c->f_pln, &c->f_pl, &c->f_sl, &c->f_dl, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed };
+    for (DevBuf * b : bufs) if (b->p) hipFree(b->p);
+    for (DevBuf & b : c->qb) if (b.p) hipFree(b.p);
+    for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
+    for (DevCounters * h : c->pending_host) hipHostFree(h);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return RTX_OK;
+}
+
+extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node * nodes, int32_t node_count,
+                               const rtx_triangle_hot * tri_hot, const rtx_triangle_cold * tri_cold,
+                               int32_t triangle_count, int32_t material_offset) {
+    if (!c || blas_id < 0 || blas_id >= (1 << 20) || !nodes || node_count <= 0 || triangle_count < 0 || (triangle_count > 0 && (!tri_hot || !tri_cold)))
+        return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    // every leaf must address triangles inside the arrays, every inner node children inside the node array
+    for (int i = 0; i < node_count; i++) {
+        if (i == 1) continue;   // index 1 is never used (BVHBuilders.h:20-21)
+        const int cnt = nodes[i].count & 0x3fffffff, f = nodes[i].left_or_first;
+        if (cnt > 0) { if (f < 0 || (int64_t)f + cnt > triangle_count) return RTX_ERR_INVALID_ARG; }
+        else if (f < 0 || f + 1 >= node_count) return RTX_ERR_INVALID_ARG;
+    }
+    if ((size_t)blas_id >= c->h_blas.size()) { c->h_blas.resize(blas_id + 1); c->blas_allocs.resize(blas_id + 1); for (auto & b : c->h_blas) if (!b.nodes) memset(&b, 0, sizeof(b)); }
+    for (void * p : c->blas_allocs[blas_id]) hipFree(p);
+    c->blas_allocs[blas_id].clear();
+
+    std::vector<float4> nd; convert_nodes(nodes, node_count, nd);
+    std::vector<float4> th((size_t)3 * (triangle_count > 0 ? triangle_count : 1));
+    for (int i = 0; i < triangle_count; i++) {
+        th[3 * i]     = make_float4(tri_hot[i].position_0[0], tri_hot[i].position_0[1], tri_hot[i].position_0[2], 0.0f);
+        th[3 * i + 1] = make_float4(tri_hot[i].position_edge_1[0], tri_hot[i].position_edge_1[1], tri_hot[i].position_edge_1[2], 0.0f);
+        th[3 * i + 2] = make_float4(tri_hot[i].position_edge_2[0], tri_hot[i].position_edge_2[1], tri_hot[i].position_edge_2[2], 0.0f);
+    }
+    void * dn = nullptr, * dt = nullptr, * dc = nullptr;
+    HIP_OK(c, hipMalloc(&dn, nd.size() * 16)); c->blas_allocs[blas_id].push_back(dn);
+    HIP_OK(c, hipMalloc(&dt, th.size() * 16)); c->blas_allocs[blas_id].push_back(dt);
+    HIP_OK(c, hipMalloc(&dc, (size_t)(triangle_count > 0 ? triangle_count : 1) * sizeof(rtx_triangle_cold))); c->blas_allocs[blas_id].push_back(dc);
+    HIP_OK(c, hipMemcpy(dn, nd.data(), nd.size() * 16, hipMemcpyHostToDevice));
+    HIP_OK(c, hipMemcpy(dt, th.data(), th.size() * 16, hipMemcpyHostToDevice));
+    if (triangle_count) HIP_OK(c, hipMemcpy(dc, tri_cold, (size_t)triangle_count * sizeof(rtx_triangle_cold), hipMemcpyHostToDevice));
+    DevBlas & B = c->h_blas[blas_id];
+    B.nodes = (const float4 *)dn; B.tri_hot = (const float4 *)dt; B.tri_cold = (const rtx_triangle_cold *)dc;
+    B.node_count = node_count; B.tri_count = triangle_count; B.material_offset = material_offset; B.pad = 0;
+    return upload(c, c->d_blas, c->h_blas.data(), c->h_blas.size() * sizeof(DevBlas));
+}
+
+extern "C" int rtx_upload_materials(rtx_ctx * c, const rtx_material * materials, int32_t count) {
+    if (!c || !materials || count <= 0) return RTX_ERR_INVALID_ARG;
+    if (count > RTX_MAX_MATERIALS) return RTX_ERR_LIMIT;       // "Max Material limit reached!" Material.h:33-37
+    hipSetDevice(c->cfg.device);
+    c->material_count = count;
+    return upload(c, c->d_materials, materials, (size_t)count * sizeof(rtx_material));
+}
+
+extern "C" int rtx_upload_texture(rtx_ctx * c, int32_t texture_id, const rtx_texture_desc * desc, const float * texels_rgb, int64_t texel_count) {
+    if (!c || texture_id < 0 || texture_id >= 4096 || !desc || !texels_rgb) return RTX_ERR_INVALID_ARG;
+    if (desc->width <= 0 || desc->height <= 0 || desc->mip_levels < 1 || desc->mip_levels > RTX_MAX_MIP_LEVELS) return RTX_ERR_INVALID_ARG;
+    for (int l = 0; l < desc->mip_levels; l++) {
+        const int64_t lw = desc->width >> l, lh = desc->height >> l;
+        if (lw < 1 || lh < 1 || desc->mip_offsets[l] < 0 || desc->mip_offsets[l] + lw * lh > texel_count) return RTX_ERR_INVALID_ARG;
+    }
+    hipSetDevice(c->cfg.device);
+    if ((size_t)texture_id >= c->h_tex.size()) { size_t old = c->h_tex.size(); c->h_tex.resize(texture_id + 1); for (size_t i = old; i < c->h_tex.size(); i++) memset(&c->h_tex[i], 0, sizeof(DevTexture)); }
+    void * d = nullptr;
+    HIP_OK(c, hipMalloc(&d, (size_t)texel_count * 12));
+    c->tex_allocs.push_back(d);
+    HIP_OK(c, hipMemcpy(d, texels_rgb, (size_t)texel_count * 12, hipMemcpyHostToDevice));
+    c->h_tex[texture_id].desc = *desc;
+    c->h_tex[texture_id].texels = (const float *)d;
+    return upload(c, c->d_textures, c->h_tex.data(), c->h_tex.size() * sizeof(DevTexture));
+}
+
+extern "C" int rtx_upload_sky(rtx_ctx * c, const float * texels_rgb, int32_t size) {
+    if (!c || !texels_rgb || size <= 0 || size > 16384) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    // Sky::sample clamps the texel index to size*size INCLUSIVE (Sky.cpp:45): one zero texel of padding
+    std::vector<float> padded((size_t)size * size * 3 + 3, 0.0f);
+    memcpy(padded.data(), texels_rgb, (size_t)size * size * 12);
+    c->sky_size = size;
+    return upload(c, c->d_sky, padded.data(), padded.size() * 4);
+}
+
+extern "C" int rtx_set_frame(rtx_ctx * c, const rtx_frame * f) {
+    if (!c || !f) return RTX_ERR_INVALID_ARG;
+    if (f->tlas_node_count < 0 || f->instance_count < 0 || f->sphere_count < 0 || f->plane_count < 0 || f->tlas_index_count < 0 ||
+        f->point_light_count < 0 || f->spot_light_count < 0 || f->directional_light_count < 0) return RTX_ERR_INVALID_ARG;
+    if ((f->tlas_node_count && !f->tlas_nodes) || (f->instance_count && !f->instances) || (f->tlas_index_count && !f->tlas_indices) ||
+        (f->sphere_count && !f->spheres) || (f->plane_count && !f->planes) || (f->point_light_count && !f->point_lights) ||
+        (f->spot_light_count && !f->spot_lights) || (f->directional_light_count && !f->directional_lights)) return RTX_ERR_INVALID_ARG;
+    if (f->instance_count >= (1 << 28) || f->sphere_count >= (1 << 28) || f->plane_count >= (1 << 28)) return RTX_ERR_LIMIT;
+    hipSetDevice(c->cfg.device);
+    // validate the TLAS against the instance table and the instances against the uploaded BLAS set
+    for (int i = 0; i < f->tlas_node_count; i++) {
+        if (i == 1) continue;
+        const int cnt = f->tlas_nodes[i].count & 0x3fffffff, first = f->tlas_nodes[i].left_or_first;
+        if (cnt > 0) { if (first < 0 || (int64_t)first + cnt > f->tlas_index_count) return RTX_ERR_INVALID_ARG; }
+        else if (first < 0 || first + 1 >= f->tlas_node_count) return RTX_ERR_INVALID_ARG;
+    }
+    for (int i = 0; i < f->tlas_index_count; i++) if (f->tlas_indices[i] < 0 || f->tlas_indices[i] >= f->instance_count) return RTX_ERR_INVALID_ARG;
+    for (int i = 0; i < f->instance_count; i++) {
+        const int b = f->instances[i].blas_id;
+        if (b < 0 || (size_t)b >= c->h_blas.size() || !c->h_blas[b].nodes) return RTX_ERR_STATE;
+    }
+    if (c->stream) hipStreamSynchronize(c->stream);      // never concurrently with rendering (Main.cpp:54-57)
+
+    std::vector<float4> nd; convert_nodes(f->tlas_nodes, f->tlas_node_count, nd);
+    int rc = upload(c, c->f_tlas, nd.data(), nd.size() * 16);
+    if (!rc) rc = upload(c, c->f_tlas_idx, f->tlas_indices, (size_t)f->tlas_index_count * 4);
+    if (!rc) rc = upload(c, c->f_inst, f->instances, (size_t)f->instance_count * sizeof(rtx_instance));
+    if (!rc) rc = upload(c, c->f_sph, f->spheres, (size_t)f->sphere_count * sizeof(rtx_sphere));
+    if (!rc) rc = upload(c, c->f_pln, f->planes, (size_t)f->plane_count * sizeof(rtx_plane));
+    if (!rc) rc = upload(c, c->f_pl, f->point_lights, (size_t)f->point_light_count * sizeof(rtx_point_light));
+    if (!rc) rc = upload(c, c->f_sl, f->spot_lights, (size_t)f->spot_light_count * sizeof(rtx_spot_light));
+    if (!rc) rc = upload(c, c->f_dl, f->directional_lights, (size_t)f->directional_light_count * sizeof(rtx_directional_light));
+    if (rc) return rc;
+
+    DevScene & s = c->scene;
+    s.width = c->cfg.width; s.height = c->cfg.height; s.bounces = c->cfg.bounces; s.stack_size = c->cfg.stack_size;
+    s.traversal_strategy = c->cfg.traversal_strategy; s.texture_mode = c->cfg.texture_mode; s.mip_filter = c->cfg.mip_filter;
+    s.diff_enabled = c->cfg.texture_mode == RTX_TEXTURE_MIPMAP;            // RAY_DIFFERENTIALS_ENABLED, Config.h:46
+    s.max_anisotropy = c->cfg.max_anisotropy;
+    s.tile_count_x = (c->cfg.width + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE;   // Window.cpp:11
+    memcpy(s.cam_pos, f->camera.position, 12); memcpy(s.cam_tl, f->camera.rotated_top_left_corner, 12);
+    memcpy(s.cam_x, f->camera.rotated_x_axis, 12); memcpy(s.cam_y, f->camera.rotated_y_axis, 12);
+    memcpy(s.ambient, f->ambient, 12);
+    s.blas = (const DevBlas *)c->d_blas.p; s.blas_count = (int)c->h_blas.size();
+    s.materials = (const rtx_material *)c->d_materials.p; s.material_count = c->material_count;
+    s.textures = (const DevTexture *)c->d_textures.p; s.texture_count = (int)c->h_tex.size();
+    s.sky = (const float *)c->d_sky.p; s.sky_size = c->sky_size;
+    s.ewa_table = (const float *)c->d_ewa.p;
+    s.tlas_nodes = (const float4 *)c->f_tlas.p; s.tlas_node_count = f->tlas_node_count;
+    s.tlas_indices = (const int32_t *)c->f_tlas_idx.p; s.tlas_index_count = f->tlas_index_count;
+    s.instances = (const rtx_instance *)c->f_inst.p; s.instance_count = f->instance_count;
+    s.spheres = (const rtx_sphere *)c->f_sph.p; s.sphere_count = f->sphere_count;
+    s.planes = (const rtx_plane *)c->f_pln.p; s.plane_count = f->plane_count;
+    s.point_lights = (const rtx_point_light *)c->f_pl.p; s.point_light_count = f->point_light_count;
+    s.spot_lights = (const rtx_spot_light *)c->f_sl.p; s.spot_light_count = f->spot_light_count;
+    s.dir_lights = (const rtx_directional_light *)c->f_dl.p; s.dir_light_count = f->directional_light_count;
+    s.light_count = f->point_light_count + f->spot_light_count + f->directional_light_count;
+    c->frame_set = true;
+    return RTX_OK;
+}
+
+// ---- queue memory ------------------------------------------------------------------------------------
+static int plan_batch(rtx_ctx * c, int tiles, int & out_tiles) {
+    // worst case: every hit spawns two children -> level d holds P * 2^d rays
+    const int levels = c->cfg.bounces + 1;
+    const long long per_tile = 1024ll * ((1ll << levels) - 1);
+    long long t = SLOT_BUDGET / per_tile;
+    if (t < 1) t = 1;
+    out_tiles = (int)(t < tiles ? t : tiles);
+    return RTX_OK;
+}
+
+static int alloc_queues(rtx_ctx * c, int batch_tiles) {
+    const int levels = c->cfg.bounces + 1;
+    const long long P = 1024ll * batch_tiles;
+    long long total = 0;
+    for (int d = 0; d <= RTX_MAX_LEVELS; d++) {
+        long long cap = d < levels ? (P << d) : 0;
+        c->q.level_base[d] = (int32_t)total; c->q.level_cap[d] = (int32_t)cap;
+        total += cap;
+    }
+    if (total >= (1ll << 31)) { c->err = "batch too large"; return RTX_ERR_LIMIT; }
+    const int nL = c->scene.light_count;
+    long long stotal = 0;
+    for (int d = 0; d <= RTX_MAX_LEVELS; d++) { c->q.shadow_base[d] = (int32_t)stotal; stotal += (long long)c->q.level_cap[d] * nL; }
+    if (stotal >= (1ll << 31)) { c->err = "shadow queue too large"; return RTX_ERR_LIMIT; }
+    const size_t slots = (size_t)total, sslots = (size_t)(stotal > 0 ? stotal : 1);
+    int rc = 0, k = 0;
+    // rays of level 0 are never stored, but the arrays are indexed by global slot for simplicity of addressing
+    void ** f4[] = { (void **)&c->q.r0, (void **)&c->q.r1, (void **)&c->q.r2, (void **)&c->q.r3, (void **)&c->q.r4, (void **)&c->q.h0,
+                     (void **)&c->q.n0, (void **)&c->q.n1, (void **)&c->q.n2, (void **)&c->q.n3, (void **)&c->q.c0, (void **)&c->q.c1 };
+    for (void ** p : f4) { if (!rc) rc = ensure(c, c->qb[k], slots * 16); *p = c->qb[k].p; k++; }
+    if (!rc) rc = ensure(c, c->qb[k], slots * 4); c->q.h1 = (int32_t *)c->qb[k].p; k++;
+    void ** s4[] = { (void **)&c->q.s0, (void **)&c->q.s1, (void **)&c->q.sc };
+    for (void ** p : s4) { if (!rc) rc = ensure(c, c->qb[k], sslots * 16); *p = c->qb[k].p; k++; }
+    if (!rc) rc = ensure(c, c->qb[k], sslots * 4); c->q.socc = (uint32_t *)c->qb[k].p; k++;
+    c->q.spill = (int32_t *)c->d_spill.p;
+    c->q.counters = (DevCounters *)c->d_counters.p;
+    c->q.fb_rgb = (float *)c->d_fb_rgb.p;
+    c->q.fb_packed = (uint32_t *)c->d_fb_packed.p;
+    return rc;
+}
+
+__global__ void k_begin_batch(DevCounters * ctr, uint32_t primary_slots) {
+    // zero everything except the accumulating stats / work counters and the error flags
+    const int i = threadIdx.x;
+    if (i <= RTX_MAX_LEVELS) { ctr->ray_count[i] = (i == 0) ? primary_slots : 0u; ctr->lit_count[i] = 0u; ctr->fetch_closest[i] = 0u; ctr->fetch_any[i] = 0u; }
+}
+
+static hipEvent_t next_event(rtx_ctx * c) {
+    if (c->event_next == c->event_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->event_pool.push_back(e); }
+    return c->event_pool[c->event_next++];
+}
+
+template <typename F>
+static void launch_timed(rtx_ctx * c, const char * name, F && launch) {
+    if (c->timing) {
+        KernelTime kt; kt.name = name; kt.a = next_event(c); kt.b = next_event(c);
+        hipEventRecord(kt.a, c->stream);
+        launch();
+        hipEventRecord(kt.b, c->stream);
+        c->times.push_back(kt);
+    } else launch();
+}
+
+extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_stride, int32_t tile_count, uint32_t flags) {
+    if (!c || first_tile < 0 || tile_stride < 1 || tile_count < 0) return RTX_ERR_INVALID_ARG;
+    if (!c->frame_set) { c->err = "rtx_render_tiles before rtx_set_frame"; return RTX_ERR_STATE; }
+    const int tcx = (c->cfg.width + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE, tcy = (c->cfg.height + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE;
+    if (tile_count > 0 && first_tile + (int64_t)(tile_count - 1) * tile_stride >= (int64_t)tcx * tcy) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    const bool count_work = (flags & RTX_RENDER_COUNT_WORK) != 0;
+
+    // stats of this call: reset accumulators (WorkerThread.cpp:120 zeroes them per frame)
+    HIP_OK(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), c->stream));
+    c->times.clear(); c->event_next = 0;
+    if (tile_count == 0) { c->stats_pending = true; return RTX_OK; }
+
+    int batch_tiles = 0;
+    plan_batch(c, tile_count, batch_tiles);
+    int rc = alloc_queues(c, batch_tiles);
+    if (rc) return rc;
+    const int levels = c->cfg.bounces + 1;
+    const int stream_blocks = c->n_cu * 8;
+
+    for (int done = 0; done < tile_count; done += batch_tiles) {
+        const int n = (tile_count - done) < batch_tiles ? (tile_count - done) : batch_tiles;
+        DevQueues q = c->q;
+        q.first_tile = first_tile + done * tile_stride; q.tile_stride = tile_stride; q.tile_count = n; q.primary_slots = n * 1024;
+        const DevScene sc = c->scene;
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, q.counters, (uint32_t)q.primary_slots);
+        for (int level = 0; level < levels; level++) {
+            launch_timed(c, "k_trace_closest", [&] {
+                if (count_work) hipLaunchKernelGGL((k_trace<false, true>),  dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else            hipLaunchKernelGGL((k_trace<false, false>), dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+            });
+            launch_timed(c, "k_shade", [&] {
+                if (count_work) hipLaunchKernelGGL((k_shade<true>),  dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
+                else            hipLaunchKernelGGL((k_shade<false>), dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
+            });
+            if (sc.light_count > 0) launch_timed(c, "k_trace_any", [&] {
+                if (count_work) hipLaunchKernelGGL((k_trace<true, true>),  dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else            hipLaunchKernelGGL((k_trace<true, false>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+            });
+        }
+        for (int level = levels - 1; level >= 0; level--)
+            launch_timed(c, "k_resolve", [&] { hipLaunchKernelGGL(k_resolve, dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level); });
+    }
+    HIP_OK(c, hipGetLastError());
+    c->stats_pending = true;
+    return RTX_OK;
+}
+
+extern "C" int rtx_synchronize(rtx_ctx * c) {
+    if (!c) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    return RTX_OK;
+}
+
+extern "C" int rtx_get_stats(rtx_ctx * c, rtx_stats * stats, rtx_work_counters * work) {
+    if (!c) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    if (c->stats_pending) {
+        DevCounters h;
+        HIP_OK(c, hipMemcpyAsync(&h, c->d_counters.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        c->stats_acc.num_primary_rays = h.stats[0]; c->stats_acc.num_shadow_rays = h.stats[1];
+        c->stats_acc.num_reflection_rays = h.stats[2]; c->stats_acc.num_refraction_rays = h.stats[3];
+        memset(&c->work_acc, 0, sizeof(c->work_acc));
+        memcpy(&c->work_acc, h.work, sizeof(uint64_t) * 15);
+        c->err_flags_acc = h.error_flags;
+        c->stats_pending = false;
+    }
+    if (stats) *stats = c->stats_acc;
+    if (work)  *work  = c->work_acc;
+    if (c->err_flags_acc & ERR_STACK_OVERFLOW) { c->err = "BVH traversal stack overflow (BVH_TRAVERSAL_STACK_SIZE, Config.h:25)"; return RTX_ERR_LIMIT; }
+    if (c->err_flags_acc & ERR_QUEUE_OVERFLOW) { c->err = "ray queue overflow"; return RTX_ERR_LIMIT; }
+    return RTX_OK;
+}
+
+extern "C" int rtx_read_framebuffer(rtx_ctx * c, float * rgb_f32, uint32_t * packed_u32) {
+    if (!c) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    const size_t px = (size_t)c->cfg.width * c->cfg.height;
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    if (rgb_f32)    HIP_OK(c, hipMemcpy(rgb_f32, c->d_fb_rgb.p, px * 12, hipMemcpyDeviceToHost));
+    if (packed_u32) HIP_OK(c, hipMemcpy(packed_u32, c->d_fb_packed.p, px * 4, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+extern "C" int rtx_framebuffer_device_ptrs(rtx_ctx * c, void ** rgb_f32_dev, void ** packed_u32_dev) {
+    if (!c) return RTX_ERR_INVALID_ARG;
+    if (rgb_f32_dev) *rgb_f32_dev = c->d_fb_rgb.p;
+    if (packed_u32_dev) *packed_u32_dev = c->d_fb_packed.p;
+    return RTX_OK;
+}
+
+extern "C" int rtx_enable_kernel_timing(rtx_ctx * c, int32_t enable) {
+    if (!c) return RTX_ERR_INVALID_ARG;
+    c->timing = enable != 0;
+    return RTX_OK;
+}
+
+extern "C" int rtx_last_kernel_times(rtx_ctx * c, const char ** names, float * ms, int32_t capacity, int32_t * count) {
+    if (!c || !count) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    *count = (int32_t)c->times.size();
+    for (int i = 0; i < (int)c->times.size() && i < capacity; i++) {
+        float t = 0.0f;
+        hipEventElapsedTime(&t, c->times[i].a, c->times[i].b);
+        if (names) names[i] = c->times[i].name;
+        if (ms) ms[i] = t;
+    }
+    return RTX_OK;
+}
+
+// ---- unit-level entry points (parity tests of single reference functions on the device) --------------
+__global__ void k_debug_libm(int fn, const float * a, const float * b, float * out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (fn) {
+        case 0: r = rtx_acosf(a[i]); break;
+        case 1: r = rtx_atan2f(a[i], b[i]); break;
+        case 2: r = rtx_expf(a[i]); break;
+        case 3: r = rtx_log2f(a[i]); break;
+        case 4: r = rtx_atanf(a[i]); break;
+        case 5: r = (float)f2i_rn_x86(a[i]); break;
+        default: r = 1.0f / sqrtf(a[i]); break;
+    }
+    out[i] = r;
+}
+
+extern "C" int rtx_debug_libm(rtx_ctx * c, int32_t fn, const float * a, const float * b, float * out, int32_t n) {
+    if (!c || !a || !out || n <= 0) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    float * da = nullptr, * db = nullptr, * dout = nullptr;
+    HIP_OK(c, hipMalloc(&da, (size_t)n * 4)); HIP_OK(c, hipMalloc(&db, (size_t)n * 4)); HIP_OK(c, hipMalloc(&dout, (size_t)n * 4));
+    HIP_OK(c, hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(c, hipMemcpy(db, b ? b : a, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_libm, dim3((n + 255) / 256), dim3(256), 0, c->stream, fn, da, db, dout, n);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dout);
+    return RTX_OK;
+}
+
+__global__ void k_debug_texture(DevScene sc, int tex, const float * in6, float * out3, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    TexCtx tc; tc.t = &sc.textures[tex]; tc.fetches = 0;
+    const float * p = in6 + 6 * (size_t)i;
+    const v3 r = texture_sample(tc, sc, p[0], p[1], p[2], p[3], p[4], p[5]);
+    out3[3 * i] = r.x; out3[3 * i + 1] = r.y; out3[3 * i + 2] = r.z;
+}
+
+// Texture::sample (Texture.h:33-49) at n (s, t, ds_dx, ds_dy, dt_dx, dt_dy) inputs with the context's texture_mode / mip_filter
+extern "C" int rtx_debug_texture_sample(rtx_ctx * c, int32_t texture_id, const float * in6, float * out3, int32_t n) {
+    if (!c || !in6 || !out3 || n <= 0 || texture_id < 0 || (size_t)texture_id >= c->h_tex.size() || !c->h_tex[texture_id].texels) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    DevScene sc = c->scene;
+    sc.texture_mode = c->cfg.texture_mode; sc.mip_filter = c->cfg.mip_filter; sc.max_anisotropy = c->cfg.max_anisotropy;
+    sc.textures = (const DevTexture *)c->d_textures.p; sc.ewa_table = (const float *)c->d_ewa.p;
+    float * din = nullptr, * dout = nullptr;
+    HIP_OK(c, hipMalloc(&din, (size_t)n * 24)); HIP_OK(c, hipMalloc(&dout, (size_t)n * 12));
+    HIP_OK(c, hipMemcpy(din, in6, (size_t)n * 24, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_texture, dim3((n + 255) / 256), dim3(256), 0, c->stream, sc, texture_id, din, dout, n);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipMemcpy(out3, dout, (size_t)n * 12, hipMemcpyDeviceToHost));
+    hipFree(din); hipFree(dout);
+    return RTX_OK;
+}
+
+__global__ void k_debug_sky(const float * sky, int size, const float * dirs, float * out3, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const v3 r = sky_sample(sky, size, V3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));
+    out3[3 * i] = r.x; out3[3 * i + 1] = r.y; out3[3 * i + 2] = r.z;
+}
+
+// Sky::sample (Sky.cpp:28-68) at n directions
+extern "C" int rtx_debug_sky_sample(rtx_ctx * c, const float * dirs3, float * out3, int32_t n) {
+    if (!c || !dirs3 || !out3 || n <= 0) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    float * din = nullptr, * dout = nullptr;
+    HIP_OK(c, hipMalloc(&din, (size_t)n * 12)); HIP_OK(c, hipMalloc(&dout, (size_t)n * 12));
+    HIP_OK(c, hipMemcpy(din, dirs3, (size_t)n * 12, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_sky, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float *)c->d_sky.p, c->sky_size, din, dout, n);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipMemcpy(out3, dout, (size_t)n * 12, hipMemcpyDeviceToHost));
+    hipFree(din); hipFree(dout);
+    return RTX_OK;
+}

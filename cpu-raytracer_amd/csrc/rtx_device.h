@@ -1,0 +1,124 @@
+// rtx_device.h — data layout in HBM shared by the kernels and the host side of librtx_hip.so.
+//
+// Layout rules (MI355X): everything a wave streams is "SoA at float4 granularity": lane i reads
+// element i of an array of float4, so one load instruction moves 64 x 16 B = 1 KiB contiguous.
+// Gathers (BVH nodes, triangles) are 16-byte aligned float4 records: a 32-byte node is two
+// dwordx4 loads, a padded 48-byte triangle three.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rtx.h"
+
+#define RTX_MAX_LEVELS   12          // NUMBER_OF_BOUNCES + 1 wavefront levels supported
+#define RTX_LDS_STACK    32          // traversal stack entries kept in LDS per lane; deeper entries spill to HBM
+#define RTX_WAVE         64
+#define RTX_TRACE_BLOCK  256         // 4 waves per workgroup
+
+// prim codes stored in a hit record (w of h0)
+#define PRIM_NONE     0
+#define PRIM_TRI      (1 << 28)      // | instance index
+#define PRIM_SPHERE   (2 << 28)      // | sphere index
+#define PRIM_PLANE    (3 << 28)      // | plane index
+#define PRIM_KIND(p)  ((p) & (3 << 28))
+#define PRIM_INDEX(p) ((p) & ((1 << 28) - 1))
+
+// node-record flags
+#define NF_HIT      1
+#define NF_LIT      2
+#define NF_REFL     4
+#define NF_REFR     8      // refraction_mask (|Kt|^2 > 0 and bounces left)
+#define NF_TIR      16
+#define NF_ENTER    32
+
+struct DevBlas {
+    const float4 *            nodes;      // 2 x float4 per node: (min.xyz, left_or_first) (max.xyz, count)
+    const float4 *            tri_hot;    // 3 x float4 per triangle: (p0, -) (e1, -) (e2, -)
+    const rtx_triangle_cold * tri_cold;   // reference layout, 64 B
+    int32_t node_count, tri_count, material_offset, pad;
+};
+
+struct DevTexture {
+    rtx_texture_desc desc;
+    const float *    texels;              // float3 per texel
+};
+
+struct DevCounters {
+    uint32_t ray_count[RTX_MAX_LEVELS + 1];       // rays queued per level (level 0 = primary slots)
+    uint32_t lit_count[RTX_MAX_LEVELS + 1];       // lit hits per level (shadow-slot rank allocator)
+    uint32_t fetch_closest[RTX_MAX_LEVELS + 1];   // dynamic-fetch heads of the persistent trace kernels
+    uint32_t fetch_any[RTX_MAX_LEVELS + 1];
+    uint32_t error_flags;                         // bit0: traversal stack overflow, bit1: queue overflow
+    uint32_t pad[3];
+    unsigned long long stats[4];                  // primary, shadow, reflection, refraction
+    unsigned long long work[20];                  // rtx_work_counters order
+};
+
+#define ERR_STACK_OVERFLOW 1u
+#define ERR_QUEUE_OVERFLOW 2u
+
+// work[] indices (order of rtx_work_counters)
+enum { W_CLOSEST_RAYS, W_ANY_RAYS, W_TLAS_C, W_TLAS_A, W_BLAS_C, W_BLAS_A, W_INST_C, W_INST_A, W_TRI_C, W_TRI_A,
+       W_TRI_HITS, W_SHADED, W_SKY, W_TEXELS, W_SPAWNED };
+
+struct DevScene {
+    int32_t width, height, bounces, stack_size;
+    int32_t traversal_strategy, texture_mode, mip_filter, diff_enabled;
+    float   max_anisotropy;
+    int32_t tile_count_x;
+    // camera (Camera.h:10-23)
+    float cam_pos[3], cam_tl[3], cam_x[3], cam_y[3];
+    float ambient[3];
+
+    const DevBlas *       blas;       int32_t blas_count;
+    const rtx_material *  materials;  int32_t material_count;
+    const DevTexture *    textures;   int32_t texture_count;
+    const float *         sky;        int32_t sky_size;
+    const float *         ewa_table;
+
+    const float4 *        tlas_nodes;   int32_t tlas_node_count;
+    const int32_t *       tlas_indices; int32_t tlas_index_count;
+    const rtx_instance *  instances;    int32_t instance_count;
+    const rtx_sphere *    spheres;      int32_t sphere_count;
+    const rtx_plane *     planes;       int32_t plane_count;
+    const rtx_point_light *       point_lights; int32_t point_light_count;
+    const rtx_spot_light *        spot_lights;  int32_t spot_light_count;
+    const rtx_directional_light * dir_lights;   int32_t dir_light_count;
+    int32_t light_count;                // total lights = shadow rays per lit hit
+};
+
+// One render call (a batch of tiles) works on P = tile_count * 1024 primary slots.  Slots of level d
+// live at [level_base[d], level_base[d] + level_cap[d]) of every per-ray array below.
+struct DevQueues {
+    int32_t level_base[RTX_MAX_LEVELS + 1];
+    int32_t level_cap[RTX_MAX_LEVELS + 1];
+    int32_t shadow_base[RTX_MAX_LEVELS + 1];     // slot = shadow_base[d] + light * level_cap[d] + lit_rank
+    int32_t first_tile, tile_stride, tile_count, primary_slots;
+
+    // ray records, levels >= 1 (level 0 is regenerated from the pixel index): 5 x float4
+    float4 * r0;   // o.x o.y o.z d.x
+    float4 * r1;   // d.y d.z dOdx.x dOdx.y
+    float4 * r2;   // dOdx.z dOdy.x dOdy.y dOdy.z
+    float4 * r3;   // dDdx.x dDdx.y dDdx.z dDdy.x
+    float4 * r4;   // dDdy.y dDdy.z bits(pixel) bits(parent slot | refraction<<31)
+    // hit records
+    float4 *  h0;  // t u v bits(prim)
+    int32_t * h1;  // triangle index
+    // node records (written by shade, folded by resolve)
+    float4 * n0;   // albedo.xyz (or sky colour on a miss), bits(flags)
+    float4 * n1;   // Ks.xyz, F_r
+    float4 * n2;   // (Kt - 1).xyz, hit distance
+    float4 * n3;   // bits(lit rank), bits(pixel), bits(parent slot | refraction<<31), -
+    float4 * c0;   // reflection child's returned colour (written by the child's k_resolve)
+    float4 * c1;   // refraction child's returned colour, refraction child's hit distance
+    // shadow records
+    float4 *   s0; // origin.xyz, max distance
+    float4 *   s1; // direction.xyz, -
+    float4 *   sc; // unshadowed light contribution.xyz, -
+    uint32_t * socc; // 1 = occluded
+
+    int32_t *     spill;          // traversal stack spill: [(entry - RTX_LDS_STACK) * spill_threads + thread]
+    int32_t       spill_threads;
+    DevCounters * counters;
+    float *       fb_rgb;         // W*H*3
+    uint32_t *    fb_packed;      // W*H
+};

@@ -1,0 +1,484 @@
+// rtx_shade.h — the shading half of Raytracer::bounce (Raytracer.cpp:87-400) as two streaming kernels.
+//
+//   k_shade(level)    one lane per ray of the level: rebuild the RayHit of the closest hit
+//                     (triangle_trace / Sphere::trace / Plane::trace accept branches), albedo
+//                     (Material::get_albedo -> Texture::sample), one shadow ray + unshadowed light
+//                     contribution per light, and the reflected / refracted child rays with their
+//                     ray differentials.  Queue appends are wave-compacted: ballot, popcount prefix,
+//                     one atomicAdd per wave.
+//   k_resolve(level)  folds a level bottom-up in EXACTLY the reference's evaluation order
+//                     (result = diffuse*albedo; += Ks*C_refl; TIR / Beer / Schlick blend), so the
+//                     colours are bit-identical to the recursion, then hands the colour to the
+//                     parent's record or, at level 0, to Window::plot.
+#pragma once
+#include "rtx_math.h"
+#include "rtx_device.h"
+#include "rtx_texture.h"
+#include "rtx_trace.h"
+
+#define RTX_SHADE_BLOCK 256
+
+struct HitFull {          // RayHit, RayHit.h:4-36
+    v3 point, normal;
+    int material_id;
+    float u, v, ds_dx, ds_dy, dt_dx, dt_dy;
+    v3 dO_dx, dO_dy, dN_dx, dN_dy;
+};
+
+// accept branch of BottomLevelBVH::triangle_trace (BottomLevelBVH.cpp:248-308) for the winning triangle
+RTX_D void rebuild_triangle_hit(const DevScene & sc, int inst, int tri, float t, float u, float v, const RayFull & wr, HitFull & h) {
+    const rtx_instance & I = sc.instances[inst];
+    const DevBlas & B = sc.blas[I.blas_id];
+    // Mesh::trace, Mesh.cpp:17-31
+    RayFull r;
+    r.o = xform_pos(I.world_inv, wr.o);
+    r.d = xform_dir(I.world_inv, wr.d);
+    r.dO_dx = xform_dir(I.world_inv, wr.dO_dx);
+    r.dO_dy = xform_dir(I.world_inv, wr.dO_dy);
+    r.dD_dx = xform_dir(I.world_inv, wr.dD_dx);
+    r.dD_dy = xform_dir(I.world_inv, wr.dD_dy);
+
+    const float4 e1 = B.tri_hot[3 * tri + 1], e2 = B.tri_hot[3 * tri + 2];
+    const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
+    const rtx_triangle_cold & tc = B.tri_cold[tri];
+    const v3 n_edge_1 = v3p(tc.normal_edge_1), n_edge_2 = v3p(tc.normal_edge_2);
+    const v3 n = vadd(vadd(v3p(tc.normal_0), vmuls(n_edge_1, u)), vmuls(n_edge_2, v));
+
+    h.point  = xform_pos(I.world, vadd(r.o, vmuls(r.d, t)));
+    h.normal = xform_dir(I.world, vnormalize(n));
+    h.material_id = B.material_offset + tc.material_id;
+    const float te1x = tc.tex_coord_edge_1[0], te1y = tc.tex_coord_edge_1[1];
+    const float te2x = tc.tex_coord_edge_2[0], te2y = tc.tex_coord_edge_2[1];
+    h.u = (tc.tex_coord_0[0] + u * te1x) + v * te2x;
+    h.v = (tc.tex_coord_0[1] + u * te1y) + v * te2y;
+
+    if (sc.diff_enabled) {
+        const float one_over_k = 1.0f / vdot(vcross(edge_1, edge_2), r.d);
+        const v3 _q = vmadd_s(r.dD_dx, t, r.dO_dx);
+        const v3 _r = vmadd_s(r.dD_dy, t, r.dO_dy);
+        const v3 c_u = vcross(edge_2, r.d);
+        const v3 c_v = vcross(r.d, edge_1);
+        const float du_dx = one_over_k * vdot(c_u, _q);
+        const float du_dy = one_over_k * vdot(c_u, _r);
+        const float dv_dx = one_over_k * vdot(c_v, _q);
+        const float dv_dy = one_over_k * vdot(c_v, _r);
+        h.dO_dx = vadd(vmuls(edge_1, du_dx), vmuls(edge_2, dv_dx));
+        h.dO_dy = vadd(vmuls(edge_1, du_dy), vmuls(edge_2, dv_dy));
+        const v3 dn_dx = vadd(vmuls(n_edge_1, du_dx), vmuls(n_edge_2, dv_dx));
+        const v3 dn_dy = vadd(vmuls(n_edge_1, du_dy), vmuls(n_edge_2, dv_dy));
+        const float n_dot_n = vdot(n, n);
+        const float N_denom = (1.0f / sqrtf(n_dot_n)) / n_dot_n;
+        h.dN_dx = vmuls(vsub(vmuls(dn_dx, n_dot_n), vmuls(n, vdot(n, dn_dx))), N_denom);
+        h.dN_dy = vmuls(vsub(vmuls(dn_dy, n_dot_n), vmuls(n, vdot(n, dn_dy))), N_denom);
+        h.ds_dx = du_dx * te1x + dv_dx * te2x;
+        h.ds_dy = du_dy * te1x + dv_dy * te2x;
+        h.dt_dx = du_dx * te1y + dv_dx * te2y;
+        h.dt_dy = du_dy * te1y + dv_dy * te2y;
+    }
+}
+
+// accept branch of Sphere::trace, Sphere.cpp:44-89
+RTX_D void rebuild_sphere_hit(const DevScene & sc, const rtx_sphere & sp, float t, const RayFull & r, HitFull & h) {
+    const float ONE_OVER_PI = 0.31830988618f, ONE_OVER_TWO_PI = 0.15915494309f;
+    const v3 center = v3p(sp.center);
+    const float one_over_r = sp.radius_inv;
+    h.point  = vadd(r.o, vmuls(r.d, t));
+    h.normal = vmuls(vsub(h.point, center), one_over_r);
+    h.material_id = sp.material_id;
+    h.u = rtx_atan2f(h.normal.z, h.normal.x) * ONE_OVER_TWO_PI + 0.5f;
+    h.v = rtx_acosf(h.normal.y) * ONE_OVER_PI + 0.5f;
+    if (sc.diff_enabled) {
+        const v3 dPx = vmadd_s(r.dD_dx, t, r.dO_dx);
+        const v3 dPy = vmadd_s(r.dD_dy, t, r.dO_dy);
+        const float denom = -1.0f / vdot(r.d, h.normal);
+        const float dt_dx = vdot(dPx, h.normal) * denom;
+        const float dt_dy = vdot(dPy, h.normal) * denom;
+        const v3 dP_dx = vmadd_s(r.d, dt_dx, dPx);
+        const v3 dP_dy = vmadd_s(r.d, dt_dy, dPy);
+        h.dO_dx = dP_dx; h.dO_dy = dP_dy;
+        h.dN_dx = vmuls(dP_dx, one_over_r);
+        h.dN_dy = vmuls(dP_dy, one_over_r);
+        const float ds_denom = ONE_OVER_TWO_PI / (h.normal.x * h.normal.x + h.normal.z * h.normal.z + 1e-8f);
+        h.ds_dx = (h.normal.x * h.dN_dx.z - h.normal.z * h.dN_dx.x) * ds_denom;
+        h.ds_dy = (h.normal.x * h.dN_dy.z - h.normal.z * h.dN_dy.x) * ds_denom;
+        const float dt_denom = -ONE_OVER_PI * (1.0f / sqrtf(1.0f - h.normal.y * h.normal.y + 1e-8f));
+        h.dt_dx = h.dN_dx.y * dt_denom;
+        h.dt_dy = h.dN_dy.y * dt_denom;
+    }
+}
+
+// accept branch of Plane::trace, Plane.cpp:27-67
+RTX_D void rebuild_plane_hit(const DevScene & sc, const rtx_plane & pl, float t, const RayFull & r, HitFull & h) {
+    const v3 ua = v3p(pl.u_axis), va = v3p(pl.v_axis);
+    h.point  = vadd(r.o, vmuls(r.d, t));
+    h.normal = v3p(pl.normal);
+    h.material_id = pl.material_id;
+    h.u = vdot(h.point, ua);
+    h.v = vdot(h.point, va);
+    if (sc.diff_enabled) {
+        const v3 dPx = vmadd_s(r.dD_dx, t, r.dO_dx);
+        const v3 dPy = vmadd_s(r.dD_dy, t, r.dO_dy);
+        const float denom = -1.0f / (vdot(r.d, h.normal) + 1e-8f);
+        const float dt_dx = vdot(dPx, h.normal) * denom;
+        const float dt_dy = vdot(dPy, h.normal) * denom;
+        const v3 dP_dx = vmadd_s(r.d, dt_dx, dPx);
+        const v3 dP_dy = vmadd_s(r.d, dt_dy, dPy);
+        h.dO_dx = dP_dx; h.dO_dy = dP_dy;
+        h.dN_dx = V3(0.0f, 0.0f, 0.0f);
+        h.dN_dy = V3(0.0f, 0.0f, 0.0f);
+        h.ds_dx = vdot(dP_dx, ua); h.ds_dy = vdot(dP_dy, ua);
+        h.dt_dx = vdot(dP_dx, va); h.dt_dy = vdot(dP_dy, va);
+    }
+}
+
+// Light::calc_lighting, Light.h:12-26
+RTX_D v3 light_calc(v3 colour, v3 normal, v3 to_light, v3 to_camera) {
+    float intensity = vdot(normal, to_light);
+    if (!(intensity > 0.0f)) return V3(0.0f, 0.0f, 0.0f);
+    const v3 half_angle = vnormalize(vadd(to_light, to_camera));
+    const float specular_factor = vdot(normal, half_angle);
+    intensity = intensity + pow2_128(specular_factor);
+    return vmuls(colour, intensity);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(RTX_SHADE_BLOCK)
+void k_shade(const DevScene sc, const DevQueues q, const int level) {
+    DevCounters * const ctr = q.counters;
+    const uint32_t count = ctr->ray_count[level];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const int bounces_left = sc.bounces - level;
+    const int nL = sc.light_count;
+    const int lit_cap = q.level_cap[level];
+    uint32_t n_shadow = 0, n_refl = 0, n_refr = 0, n_primary = 0, n_shaded = 0, n_sky = 0, n_texels = 0, n_trihit = 0;
+
+    for (uint32_t base = wave_global * 64u; base < count; base += n_waves * 64u) {
+        const uint32_t idx = base + lane;
+        bool valid = idx < count;
+        const uint32_t slot = (uint32_t)q.level_base[level] + (valid ? idx : 0u);
+
+        RayFull ray;
+        int pixel = 0, parent = -1;
+        float4 h0 = make_float4(0, 0, 0, 0); int tri = 0;
+        if (valid) { h0 = q.h0[slot]; tri = q.h1[slot]; }
+        if (valid && level == 0 && tri == -1) valid = false;          // clipped pixel of an edge tile
+        if (valid) {
+            if (level == 0) {
+                int px, py;
+                primary_pixel(sc, q, idx, px, py);
+                primary_ray(sc, px, py, ray, true);
+                pixel = py * sc.width + px;
+                n_primary++;
+            } else {
+                const float4 r0 = q.r0[slot], r1 = q.r1[slot], r2 = q.r2[slot], r3 = q.r3[slot], r4 = q.r4[slot];
+                ray.o = V3(r0.x, r0.y, r0.z); ray.d = V3(r0.w, r1.x, r1.y);
+                ray.dO_dx = V3(r1.z, r1.w, r2.x); ray.dO_dy = V3(r2.y, r2.z, r2.w);
+                ray.dD_dx = V3(r3.x, r3.y, r3.z); ray.dD_dy = V3(r3.w, r4.x, r4.y);
+                pixel = as_i(r4.z); parent = as_i(r4.w);
+            }
+        }
+        const int prim = as_i(h0.w);
+        const float t = h0.x;
+        const bool is_hit = valid && PRIM_KIND(prim) != PRIM_NONE;
+
+        int flags = 0;
+        v3 albedo = V3(0, 0, 0);
+        HitFull h; h.material_id = 0;
+        h.point = h.normal = h.dO_dx = h.dO_dy = h.dN_dx = h.dN_dy = V3(0, 0, 0);
+        h.u = h.v = h.ds_dx = h.ds_dy = h.dt_dx = h.dt_dy = 0.0f;
+        v3 Ks = V3(0, 0, 0), Kt = V3(0, 0, 0); float ior = 1.0f;
+
+        if (valid && !is_hit) {                                       // Raytracer.cpp:105-111
+            albedo = sky_sample(sc.sky, sc.sky_size, ray.d);
+            n_sky++;
+        }
+        if (is_hit) {
+            flags = NF_HIT;
+            const int kind = PRIM_KIND(prim), pi = PRIM_INDEX(prim);
+            if (kind == PRIM_TRI) { rebuild_triangle_hit(sc, pi, tri, t, h0.y, h0.z, ray, h); n_trihit++; }
+            else if (kind == PRIM_SPHERE) rebuild_sphere_hit(sc, sc.spheres[pi], t, ray, h);
+            else rebuild_plane_hit(sc, sc.planes[pi], t, ray, h);
+
+            const rtx_material & m = sc.materials[h.material_id];     // Material::get_albedo, Material.h:16-22
+            n_shaded++;
+            albedo = v3p(m.diffuse);
+            if (m.texture_id >= 0) {
+                TexCtx tc; tc.t = &sc.textures[m.texture_id]; tc.fetches = 0;
+                const bool de = sc.diff_enabled != 0;
+                const v3 tex = texture_sample(tc, sc, h.u, h.v, de ? h.ds_dx : 0.0f, de ? h.ds_dy : 0.0f, de ? h.dt_dx : 0.0f, de ? h.dt_dy : 0.0f);
+                albedo = vmul(albedo, tex);
+                n_texels += tc.fetches;
+            }
+            Ks = v3p(m.reflection); Kt = v3p(m.transmittance); ior = m.index_of_refraction;
+            if (vdot(albedo, albedo) > 0.0f) flags |= NF_LIT;         // Raytracer.cpp:143-145
+        }
+
+        // ---- shadow rays: rank allocation for lit hits (ballot + popcount prefix + one atomic) ----
+        const bool lit = (flags & NF_LIT) != 0;
+        int lit_rank = -1;
+        {
+            const unsigned long long m_lit = __ballot(lit);
+            if (m_lit) {
+                const int leader = __ffsll((long long)m_lit) - 1;
+                uint32_t b = 0;
+                if (lane == leader) b = atomicAdd(&ctr->lit_count[level], (uint32_t)__popcll(m_lit));
+                b = __shfl(b, leader);
+                if (lit) lit_rank = (int)(b + (uint32_t)__popcll(m_lit & ((1ull << lane) - 1ull)));
+            }
+        }
+        if (lit) {
+            const v3 to_camera = vnormalize(vsub(v3p(sc.cam_pos), h.point));     // Raytracer.cpp:152 (camera, not ray origin)
+            int L = 0;
+            for (int i = 0; i < sc.point_light_count; i++, L++) {                 // :155-169
+                const rtx_point_light & pl = sc.point_lights[i];
+                v3 to_light = vsub(v3p(pl.position), h.point);
+                const float d2 = vdot(to_light, to_light);
+                const float d  = sqrtf(d2);
+                to_light = vdivs(to_light, d);
+                const v3 c = vdivs(light_calc(v3p(pl.colour), h.normal, to_light, to_camera), d2);   // PointLight.h:9-11
+                const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
+                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, d);
+                q.s1[s] = make_float4(to_light.x, to_light.y, to_light.z, 0.0f);
+                q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
+            }
+            for (int i = 0; i < sc.spot_light_count; i++, L++) {                  // :172-186
+                const rtx_spot_light & sl = sc.spot_lights[i];
+                v3 to_light = vsub(v3p(sl.position), h.point);
+                const float d2 = vdot(to_light, to_light);
+                const float d  = sqrtf(d2);
+                to_light = vdivs(to_light, d);
+                v3 c = V3(0.0f, 0.0f, 0.0f);                                      // SpotLight.h:17-33
+                const float dt = vdot(to_light, v3p(sl.negative_direction));
+                if (dt > sl.outer_cutoff) {
+                    float falloff = (dt - sl.outer_cutoff) / (sl.inner_cutoff - sl.outer_cutoff);
+                    falloff = (falloff > 1.0f) ? 1.0f : falloff;
+                    c = vmuls(vdivs(light_calc(v3p(sl.colour), h.normal, to_light, to_camera), d2), falloff);
+                }
+                const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
+                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, d);
+                q.s1[s] = make_float4(to_light.x, to_light.y, to_light.z, 0.0f);
+                q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
+            }
+            for (int i = 0; i < sc.dir_light_count; i++, L++) {                   // :189-198
+                const rtx_directional_light & dl = sc.dir_lights[i];
+                const v3 nd = v3p(dl.negative_direction);
+                const v3 c = light_calc(v3p(dl.colour), h.normal, nd, to_camera);
+                const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
+                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, INFINITY);
+                q.s1[s] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+                q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
+            }
+            n_shadow += (uint32_t)nL;                                             // counted before the occlusion test (:163,180,192)
+        }
+
+        // ---- secondary rays (Raytracer.cpp:204-346) ----
+        bool spawn_refl = false, spawn_refr = false;
+        RayFull rr, rf;
+        float F_r = 0.0f;
+        v3 absorption = V3(0, 0, 0);
+        if (is_hit && bounces_left > 0) {
+            const bool reflection_mask = vdot(Ks, Ks) > 0.0f;
+            const bool refraction_mask = vdot(Kt, Kt) > 0.0f;
+            if (reflection_mask) {
+                flags |= NF_REFL; spawn_refl = true;
+                rr.o = h.point;
+                const float dn = vdot(ray.d, h.normal);
+                rr.d = vsub(ray.d, vmuls(h.normal, 2.0f * dn));                   // Math::reflect, Math.h:28-30
+                rr.dO_dx = h.dO_dx; rr.dO_dy = h.dO_dy;
+                const float dDN_dx = vdot(ray.dD_dx, h.normal) + vdot(ray.d, h.dN_dx);
+                const float dDN_dy = vdot(ray.dD_dy, h.normal) + vdot(ray.d, h.dN_dy);
+                rr.dD_dx = vsub(ray.dD_dx, vmuls(vadd(vmuls(h.dN_dx, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dx)), 2.0f));
+                rr.dD_dy = vsub(ray.dD_dy, vmuls(vadd(vmuls(h.dN_dy, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dy)), 2.0f));
+            }
+            if (refraction_mask) {
+                flags |= NF_REFR;
+                const float dot = vdot(ray.d, h.normal);
+                const bool entering = dot < 0.0f;
+                const float air = 1.0f;
+                const float n_1 = entering ? air : ior;
+                const float n_2 = entering ? ior : air;
+                float cos_theta = entering ? (0.0f - dot) : dot;
+                const v3 normal = entering ? h.normal : vneg(h.normal);
+                const float eta = n_1 / n_2;
+                const float k = 1.0f - (eta * eta * (1.0f - (cos_theta * cos_theta)));
+                if (entering) flags |= NF_ENTER;
+                if (k < 0.0f) {
+                    flags |= NF_TIR;                                              // :310-314
+                } else {
+                    spawn_refr = true;
+                    rf.o = h.point;
+                    rf.d = vadd(vmuls(ray.d, eta), vmuls(normal, (eta * cos_theta) - sqrtf(k)));   // Math::refract, Math.h:34-36
+                    rf.dO_dx = h.dO_dx; rf.dO_dy = h.dO_dy;
+                    const float dDN_dx = vdot(ray.dD_dx, h.normal) + vdot(ray.d, h.dN_dx);
+                    const float dDN_dy = vdot(ray.dD_dy, h.normal) + vdot(ray.d, h.dN_dy);
+                    const float D_dot_N = -cos_theta;
+                    const float Dprime_dot_N = -sqrtf(k);
+                    const float mu = -(eta * cos_theta + Dprime_dot_N);
+                    rf.dD_dx = vsub(vmuls(ray.dD_dx, eta), vmuls(vadds(vmul(h.dN_dx, h.normal), mu * D_dot_N), dDN_dx));   // :341-342 literally
+                    rf.dD_dy = vsub(vmuls(ray.dD_dy, eta), vmuls(vadds(vmul(h.dN_dy, h.normal), mu * D_dot_N), dDN_dy));
+                    absorption = vsub(Kt, V3(1.0f, 1.0f, 1.0f));                  // :350
+                    float r_0 = (n_1 - n_2) / (n_1 + n_2);                        // Schlick, :378-391
+                    r_0 = r_0 * r_0;
+                    if (n_1 > n_2) cos_theta = 0.0f - vdot(rf.d, normal);
+                    const float omc  = 1.0f - cos_theta;
+                    const float omc2 = omc * omc;
+                    F_r = r_0 + ((1.0f - r_0) * omc2) * (omc2 * omc);
+                }
+            }
+        }
+        {
+            const unsigned long long m_a = __ballot(spawn_refl), m_b = __ballot(spawn_refr);
+            if (m_a | m_b) {
+                const int na = __popcll(m_a), nb = __popcll(m_b);
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&ctr->ray_count[level + 1], (uint32_t)(na + nb));
+                b = __shfl(b, 0);
+                const uint32_t cap = (uint32_t)q.level_cap[level + 1];
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (spawn_refl) {
+                    const uint32_t ci = b + (uint32_t)__popcll(m_a & below);
+                    if (ci < cap) {
+                        const uint32_t cs = (uint32_t)q.level_base[level + 1] + ci;
+                        q.r0[cs] = make_float4(rr.o.x, rr.o.y, rr.o.z, rr.d.x);
+                        q.r1[cs] = make_float4(rr.d.y, rr.d.z, rr.dO_dx.x, rr.dO_dx.y);
+                        q.r2[cs] = make_float4(rr.dO_dx.z, rr.dO_dy.x, rr.dO_dy.y, rr.dO_dy.z);
+                        q.r3[cs] = make_float4(rr.dD_dx.x, rr.dD_dx.y, rr.dD_dx.z, rr.dD_dy.x);
+                        q.r4[cs] = make_float4(rr.dD_dy.y, rr.dD_dy.z, as_f(pixel), as_f((int)slot));
+                    } else atomicOr(&ctr->error_flags, ERR_QUEUE_OVERFLOW);
+                    n_refl++;
+                }
+                if (spawn_refr) {
+                    const uint32_t ci = b + (uint32_t)na + (uint32_t)__popcll(m_b & below);
+                    if (ci < cap) {
+                        const uint32_t cs = (uint32_t)q.level_base[level + 1] + ci;
+                        q.r0[cs] = make_float4(rf.o.x, rf.o.y, rf.o.z, rf.d.x);
+                        q.r1[cs] = make_float4(rf.d.y, rf.d.z, rf.dO_dx.x, rf.dO_dx.y);
+                        q.r2[cs] = make_float4(rf.dO_dx.z, rf.dO_dy.x, rf.dO_dy.y, rf.dO_dy.z);
+                        q.r3[cs] = make_float4(rf.dD_dx.x, rf.dD_dx.y, rf.dD_dx.z, rf.dD_dy.x);
+                        q.r4[cs] = make_float4(rf.dD_dy.y, rf.dD_dy.z, as_f(pixel), as_f((int)(slot | 0x80000000u)));
+                    } else atomicOr(&ctr->error_flags, ERR_QUEUE_OVERFLOW);
+                    n_refr++;
+                }
+            }
+        }
+
+        if (valid) {
+            q.n0[slot] = make_float4(albedo.x, albedo.y, albedo.z, as_f(flags));
+            if (flags & NF_HIT) {
+                q.n1[slot] = make_float4(Ks.x, Ks.y, Ks.z, F_r);
+                q.n2[slot] = make_float4(absorption.x, absorption.y, absorption.z, t);
+            }
+            q.n3[slot] = make_float4(as_f(lit_rank), as_f(pixel), as_f(parent), 0.0f);
+        }
+    }
+
+    // statistics: wave reduce, one atomic per counter per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        n_shadow += __shfl_down(n_shadow, off); n_refl += __shfl_down(n_refl, off); n_refr += __shfl_down(n_refr, off);
+        n_primary += __shfl_down(n_primary, off);
+        if (COUNT) {
+            n_shaded += __shfl_down(n_shaded, off); n_sky += __shfl_down(n_sky, off);
+            n_texels += __shfl_down(n_texels, off); n_trihit += __shfl_down(n_trihit, off);
+        }
+    }
+    if (lane == 0) {
+        if (n_primary) atomicAdd(&ctr->stats[0], (unsigned long long)n_primary);
+        if (n_shadow)  atomicAdd(&ctr->stats[1], (unsigned long long)n_shadow);
+        if (n_refl)    atomicAdd(&ctr->stats[2], (unsigned long long)n_refl);
+        if (n_refr)    atomicAdd(&ctr->stats[3], (unsigned long long)n_refr);
+        if (COUNT) {
+            atomicAdd(&ctr->work[W_SHADED], (unsigned long long)n_shaded);
+            atomicAdd(&ctr->work[W_SKY], (unsigned long long)n_sky);
+            atomicAdd(&ctr->work[W_TEXELS], (unsigned long long)n_texels);
+            atomicAdd(&ctr->work[W_TRI_HITS], (unsigned long long)n_trihit);
+            atomicAdd(&ctr->work[W_SPAWNED], (unsigned long long)(n_refl + n_refr));
+        }
+    }
+}
+
+RTX_D float clampf_ref(float v, float lo, float hi) { if (v < lo) return lo; if (v > hi) return hi; return v; }   // Math::clamp, Math.h:12-18
+
+// Window::plot, Window.h:56-65
+RTX_D uint32_t plot_pack(v3 c) {
+    const int r = f2i_rn_x86(clampf_ref(c.x * 255.0f, 0.0f, 255.0f) - 0.5f);
+    const int g = f2i_rn_x86(clampf_ref(c.y * 255.0f, 0.0f, 255.0f) - 0.5f);
+    const int b = f2i_rn_x86(clampf_ref(c.z * 255.0f, 0.0f, 255.0f) - 0.5f);
+    return (uint32_t)((r << 16) | (g << 8) | b);
+}
+
+__global__ __launch_bounds__(RTX_SHADE_BLOCK)
+void k_resolve(const DevScene sc, const DevQueues q, const int level) {
+    const DevCounters * const ctr = q.counters;
+    uint32_t count = ctr->ray_count[level];
+    if (count > (uint32_t)q.level_cap[level]) count = (uint32_t)q.level_cap[level];
+    const int nL = sc.light_count;
+    const int lit_cap = q.level_cap[level];
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
+        const uint32_t slot = (uint32_t)q.level_base[level] + idx;
+        if (level == 0 && q.h1[slot] == -1) continue;                 // clipped pixel
+        const float4 n0 = q.n0[slot], n3 = q.n3[slot];
+        const int flags = as_i(n0.w);
+        v3 colour; float distance;
+        if (!(flags & NF_HIT)) {
+            colour = V3(n0.x, n0.y, n0.z);                             // sky, Raytracer.cpp:106-110
+            distance = INFINITY;
+        } else {
+            const float4 n1 = q.n1[slot], n2 = q.n2[slot];
+            const v3 albedo = V3(n0.x, n0.y, n0.z);
+            v3 result = V3(0.0f, 0.0f, 0.0f);
+            if (flags & NF_LIT) {                                      // :146-200
+                const uint32_t rank = (uint32_t)as_i(n3.x);
+                v3 diffuse = v3p(sc.ambient);
+                for (int L = 0; L < nL; L++) {
+                    const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + rank;
+                    if (q.socc[s]) continue;
+                    const float4 c = q.sc[s];
+                    diffuse = vadd(diffuse, V3(c.x, c.y, c.z));
+                }
+                result = vmadd_v(diffuse, albedo, result);
+            }
+            v3 colour_reflection = V3(0.0f, 0.0f, 0.0f);
+            if (flags & NF_REFL) {                                     // :268-270
+                const float4 c0 = q.c0[slot];
+                colour_reflection = vmul(V3(n1.x, n1.y, n1.z), V3(c0.x, c0.y, c0.z));
+                result = vadd(result, colour_reflection);
+            }
+            if (flags & NF_REFR) {
+                if (flags & NF_TIR) {                                  // :312-314
+                    if (flags & NF_REFL) result = vadd(result, colour_reflection);
+                } else {
+                    const float4 c1 = q.c1[slot];
+                    v3 colour_refraction = V3(c1.x, c1.y, c1.z);
+                    const float refraction_distance = c1.w;
+                    if (flags & NF_ENTER) {                            // Beer, :370-376
+                        const float beer_x = rtx_expf(n2.x * refraction_distance);
+                        const float beer_y = rtx_expf(n2.y * refraction_distance);
+                        const float beer_z = rtx_expf(n2.z * refraction_distance);
+                        colour_refraction.x = colour_refraction.x * beer_x;
+                        colour_refraction.y = colour_refraction.y * beer_y;
+                        colour_refraction.z = colour_refraction.z * beer_z;
+                    }
+                    const float F_r = n1.w, F_t = 1.0f - F_r;          // :390-395
+                    const v3 blend = vadd(vmuls(colour_reflection, F_r), vmuls(colour_refraction, F_t));
+                    result = vadd(result, blend);
+                }
+            }
+            colour = result;
+            distance = n2.w;
+        }
+        if (level == 0) {
+            const int pixel = as_i(n3.y);
+            q.fb_rgb[3 * (size_t)pixel + 0] = colour.x;
+            q.fb_rgb[3 * (size_t)pixel + 1] = colour.y;
+            q.fb_rgb[3 * (size_t)pixel + 2] = colour.z;
+            q.fb_packed[pixel] = plot_pack(colour);
+        } else {
+            const uint32_t parent = (uint32_t)as_i(n3.z);
+            const uint32_t ps = parent & 0x7fffffffu;
+            if (parent & 0x80000000u) q.c1[ps] = make_float4(colour.x, colour.y, colour.z, distance);
+            else                      q.c0[ps] = make_float4(colour.x, colour.y, colour.z, 0.0f);
+        }
+    }
+}

@@ -1,0 +1,300 @@
+// rtx_trace.h — the traversal kernels: closest hit (Scene::trace_primitives) and any hit
+// (Scene::intersect_primitives) as ONE persistent-threads kernel template.
+//
+// Structure (MI355X): a fixed grid of 256-thread workgroups stays resident; every lane owns one
+// ray and a private traversal stack striped through LDS (entry e of lane l at [e][l]: conflict
+// free).  When at least RTX_REFILL_MIN lanes of a wave have retired their ray the wave refills
+// them from the HBM ray queue: a 64-bit ballot of idle lanes, one atomicAdd on the queue head by
+// the leader, and a popcount-prefix rank per lane (dynamic fetch).  The two-level walk
+// (TopLevelBVH -> Mesh -> BottomLevelBVH) runs on one stack: TLAS leaves push instance entries
+// (negative), an instance entry switches the lane to model space until the stack drops back to the
+// level it had on entry.
+//
+// Per-lane traversal ORDER is the reference's (ordered by split axis vs ray direction sign,
+// BVHNode.h:30-40; far child pushed first, TopLevelBVH.cpp:76-82, BottomLevelBVH.cpp:381-387) so
+// that equal-t ties and ulp-level culling resolve identically.
+#pragma once
+#include "rtx_math.h"
+#include "rtx_device.h"
+
+#define RTX_REFILL_MIN   16     // refill a wave when this many lanes are idle
+#define RTX_TRACE_STEPS  8      // traversal steps between refill checks
+#define RAY_EPSILON      0.005f // Ray.h:5
+
+// Slot -> pixel of a primary ray.  1024 slots per tile, a wave covers an 8x8 pixel block.
+RTX_D bool primary_pixel(const DevScene & sc, const DevQueues & q, uint32_t slot, int & px, int & py) {
+    int tile_k = slot >> 10, l = slot & 1023;
+    int tile = q.first_tile + tile_k * q.tile_stride;
+    int tx = (tile % sc.tile_count_x) * RTX_TILE_SIZE;       // WorkerThread.cpp:57-58
+    int ty = (tile / sc.tile_count_x) * RTX_TILE_SIZE;
+    int blk = l >> 6, ln = l & 63;
+    px = tx + (blk & 3) * 8 + (ln & 7);
+    py = ty + (blk >> 2) * 8 + (ln >> 3);
+    return px < sc.width && py < sc.height;                  // WorkerThread.cpp:60-61 (clipped tiles)
+}
+
+struct RayFull {
+    v3 o, d, dO_dx, dO_dy, dD_dx, dD_dy;
+};
+
+// Raytracer::render_tile, Raytracer.cpp:30-59 (lane 1)
+RTX_D void primary_ray(const DevScene & sc, int px, int py, RayFull & r, bool with_differentials) {
+    v3 ax = v3p(sc.cam_x), ay = v3p(sc.cam_y), tl = v3p(sc.cam_tl);
+    float is = (float)px, js = (float)py;
+    v3 d = vmadd_s(ax, is, vmadd_s(ay, js, tl));
+    float dd  = vdot(d, d);
+    float inv = 1.0f / sqrtf(dd);
+    r.o = v3p(sc.cam_pos);
+    r.d = vmuls(d, inv);
+    if (with_differentials) {
+        float denom = inv / dd;
+        r.dO_dx = V3(0.0f, 0.0f, 0.0f);
+        r.dO_dy = V3(0.0f, 0.0f, 0.0f);
+        r.dD_dx = vmuls(vsub(vmuls(ax, dd), vmuls(d, vdot(d, ax))), denom);
+        r.dD_dy = vmuls(vsub(vmuls(ay, dd), vmuls(d, vdot(d, ay))), denom);
+    }
+}
+
+// AABB::intersect, AABB.cpp:38-52
+RTX_D bool slab_test(float4 a, float4 b, v3 o, v3 inv, float max_distance) {
+    v3 t0 = vmul(vsub(V3(a.x, a.y, a.z), o), inv);
+    v3 t1 = vmul(vsub(V3(b.x, b.y, b.z), o), inv);
+    v3 tmin = V3(fmin_ref(t0.x, t1.x), fmin_ref(t0.y, t1.y), fmin_ref(t0.z, t1.z));
+    v3 tmax = V3(fmax_ref(t0.x, t1.x), fmax_ref(t0.y, t1.y), fmax_ref(t0.z, t1.z));
+    float t_near = fmax_ref(fmax_ref(RAY_EPSILON, tmin.x), fmax_ref(tmin.y, tmin.z));
+    float t_far  = fmin_ref(fmin_ref(max_distance, tmax.x), fmin_ref(tmax.y, tmax.z));
+    return t_near < t_far;
+}
+
+// Sphere::trace hit test only (Sphere.cpp:9-42); attributes are rebuilt in the shade kernel
+RTX_D bool sphere_closest(const rtx_sphere & sp, v3 o, v3 d, float tbest, float & t_out) {
+    v3 oc = vsub(o, v3p(sp.center));
+    float a = vdot(d, d);
+    float b = 2.0f * vdot(oc, d);
+    float c = vdot(oc, oc) - sp.radius_squared;
+    float disc = b * b - 4.0f * a * c;
+    if (!(disc >= 0.0f)) return false;
+    float sqrt_d    = sqrtf(disc);
+    float inv_denom = -(1.0f / (2.0f * a));
+    float t0 = (b + sqrt_d) * inv_denom;
+    float t1 = (b - sqrt_d) * inv_denom;
+    float t = (t0 > RAY_EPSILON) ? t0 : t1;
+    if (!((t > RAY_EPSILON) & (t < tbest))) return false;
+    t_out = t;
+    return true;
+}
+// Sphere::intersect, Sphere.cpp:92-112
+RTX_D bool sphere_any(const rtx_sphere & sp, v3 o, v3 d, float max_distance) {
+    v3 c = vsub(v3p(sp.center), o);
+    float t = vdot(c, d);
+    v3 Q = vsub(c, vmuls(d, t));
+    float p2 = vdot(Q, Q);
+    float rs = sp.radius_squared;
+    if (!(p2 < rs)) return false;
+    t = t - sqrtf(rs - p2);
+    return (t > RAY_EPSILON) & (t < max_distance);
+}
+// Plane::trace / Plane::intersect distance, Plane.cpp:18,75
+RTX_D float plane_t(const rtx_plane & pl, v3 o, v3 d) {
+    v3 n = v3p(pl.normal);
+    return -(vdot(n, o) + pl.distance) / vdot(n, d);
+}
+
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(RTX_TRACE_BLOCK)
+void k_trace(const DevScene sc, const DevQueues q, const int level) {
+    __shared__ int lds_stack[RTX_TRACE_BLOCK / RTX_WAVE][RTX_LDS_STACK][RTX_WAVE];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int * const stk = &lds_stack[wave][0][lane];
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    int * const spill = q.spill + gtid;
+    const int spill_stride = q.spill_threads;
+
+    DevCounters * const ctr = q.counters;
+    const uint32_t total = ANY ? ctr->lit_count[level] * (uint32_t)sc.light_count : ctr->ray_count[level];
+    uint32_t * const head = ANY ? &ctr->fetch_any[level] : &ctr->fetch_closest[level];
+    const int lit_cap = q.level_cap[level];
+    const uint32_t lit_n = ctr->lit_count[level];
+
+    // per-lane ray state
+    bool has_ray = false;
+    uint32_t out_slot = 0;
+    v3 wo = V3(0, 0, 0), wd = wo, winv = wo;       // world-space ray
+    v3 co = wo, cd = wo, cinv = wo;                // ray in the space being traversed
+    float tcur = 0.0f;                             // closest t so far (ANY: max distance)
+    int best_prim = PRIM_NONE, best_tri = 0; float best_u = 0.0f, best_v = 0.0f;
+    int sp = 0, floor_sp = -1, cur_inst = 0;
+    const float4 * cur_nodes = sc.tlas_nodes;
+    const float4 * cur_tris  = nullptr;
+    uint32_t n_tlas = 0, n_blas = 0, n_inst = 0, n_tri = 0, n_rays = 0, n_stackerr = 0;
+
+    auto push = [&](int e) {
+        if (sp < RTX_LDS_STACK) stk[sp * RTX_WAVE] = e;
+        else if (sp < RTX_MAX_STACK) spill[(sp - RTX_LDS_STACK) * spill_stride] = e;
+        else { n_stackerr = 1; return; }
+        sp++;
+    };
+    auto pop = [&]() -> int {
+        sp--;
+        return (sp < RTX_LDS_STACK) ? stk[sp * RTX_WAVE] : spill[(sp - RTX_LDS_STACK) * spill_stride];
+    };
+
+    bool exhausted = false;
+    for (;;) {
+        // ---------------- refill idle lanes from the queue (ballot + prefix rank) ----------------
+        const unsigned long long idle = __ballot(!has_ray);
+        const int n_idle = __popcll(idle);
+        if (!exhausted && n_idle >= RTX_REFILL_MIN) {
+            const int leader = __ffsll((long long)idle) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(head, (uint32_t)n_idle);
+            base = __shfl(base, leader);
+            if (base + (uint32_t)n_idle >= total) exhausted = true;
+            const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!has_ray && idx < total) {
+                bool live = true;
+                if (ANY) {
+                    // shadow slot order: light-major within the level, idx = light * lit_n + rank
+                    const uint32_t light = idx / lit_n, rank = idx - light * lit_n;
+                    out_slot = (uint32_t)q.shadow_base[level] + light * (uint32_t)lit_cap + rank;
+                    const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot];
+                    wo = V3(s0.x, s0.y, s0.z); tcur = s0.w; wd = V3(s1.x, s1.y, s1.z);
+                } else {
+                    out_slot = (uint32_t)q.level_base[level] + idx;
+                    if (level == 0) {
+                        int px, py;
+                        live = primary_pixel(sc, q, idx, px, py);
+                        RayFull r;
+                        if (live) { primary_ray(sc, px, py, r, false); wo = r.o; wd = r.d; }
+                    } else {
+                        const float4 r0 = q.r0[out_slot], r1 = q.r1[out_slot];
+                        wo = V3(r0.x, r0.y, r0.z); wd = V3(r0.w, r1.x, r1.y);
+                    }
+                    tcur = INFINITY;
+                    best_prim = PRIM_NONE; best_tri = 0; best_u = 0.0f; best_v = 0.0f;
+                }
+                if (live) {
+                    if (COUNT) n_rays++;
+                    bool done = false;
+                    // Scene::trace_primitives / intersect_primitives: spheres, then planes, then the TLAS (Scene.cpp:173-190)
+                    for (int i = 0; i < sc.sphere_count; i++) {
+                        if (ANY) { if (sphere_any(sc.spheres[i], wo, wd, tcur)) { done = true; break; } }
+                        else { float t; if (sphere_closest(sc.spheres[i], wo, wd, tcur, t)) { tcur = t; best_prim = PRIM_SPHERE | i; } }
+                    }
+                    if (!done) for (int i = 0; i < sc.plane_count; i++) {
+                        const float t = plane_t(sc.planes[i], wo, wd);
+                        if (ANY) { if ((t > RAY_EPSILON) & (t < tcur)) { done = true; break; } }
+                        else if ((t > RAY_EPSILON) & (t < tcur)) { tcur = t; best_prim = PRIM_PLANE | i; }
+                    }
+                    if (ANY && done) {
+                        q.socc[out_slot] = 1u;
+                    } else if (sc.tlas_node_count > 0) {
+                        winv = vrcp(wd);
+                        co = wo; cd = wd; cinv = winv;
+                        cur_nodes = sc.tlas_nodes; floor_sp = -1;
+                        sp = 0; push(0);
+                        has_ray = true;
+                    } else {
+                        if (ANY) q.socc[out_slot] = 0u;
+                        else { q.h0[out_slot] = make_float4(tcur, 0.0f, 0.0f, as_f(best_prim)); q.h1[out_slot] = 0; }
+                    }
+                } else if (!ANY) {
+                    q.h0[out_slot] = make_float4(INFINITY, 0.0f, 0.0f, as_f(PRIM_NONE));   // clipped pixel: never shaded
+                    q.h1[out_slot] = -1;
+                }
+            }
+        }
+        if (__ballot(has_ray) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---------------- traverse ----------------
+        for (int it = 0; it < RTX_TRACE_STEPS; it++) {
+            if (!has_ray) continue;
+            if (floor_sp >= 0 && sp == floor_sp) {          // BottomLevelBVH::trace returned: back to world space
+                floor_sp = -1; co = wo; cd = wd; cinv = winv; cur_nodes = sc.tlas_nodes;
+            }
+            if (sp == 0) {                                  // ray finished
+                if (ANY) q.socc[out_slot] = 0u;
+                else { q.h0[out_slot] = make_float4(tcur, best_u, best_v, as_f(best_prim)); q.h1[out_slot] = best_tri; }
+                has_ray = false;
+                continue;
+            }
+            const int e = pop();
+            if (e < 0) {
+                // Mesh::trace / Mesh::intersect (Mesh.cpp:17-40): ray into model space
+                const int inst = sc.tlas_indices[~e];
+                const rtx_instance & I = sc.instances[inst];
+                co = xform_pos(I.world_inv, wo);
+                cd = xform_dir(I.world_inv, wd);
+                cinv = vrcp(cd);
+                const DevBlas & B = sc.blas[I.blas_id];
+                cur_nodes = B.nodes; cur_tris = B.tri_hot; cur_inst = inst;
+                floor_sp = sp;
+                push(0);
+                if (COUNT) n_inst++;
+                continue;
+            }
+            const float4 na = cur_nodes[2 * e], nb = cur_nodes[2 * e + 1];
+            if (COUNT) { if (floor_sp >= 0) n_blas++; else n_tlas++; }
+            if (!slab_test(na, nb, co, cinv, tcur)) continue;
+            const int first = as_i(na.w), cnt = as_i(nb.w);
+            if ((cnt & 0x3fffffff) > 0) {
+                if (floor_sp >= 0) {
+                    // BLAS leaf: triangle_trace / triangle_intersect (BottomLevelBVH.cpp:214-346)
+                    for (int i = first; i < first + cnt; i++) {
+                        if (COUNT) n_tri++;
+                        const float4 p0 = cur_tris[3 * i], e1 = cur_tris[3 * i + 1], e2 = cur_tris[3 * i + 2];
+                        const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
+                        const v3 h = vcross(cd, edge_2);
+                        const float a = vdot(edge_1, h);
+                        const float f = 1.0f / a;
+                        const v3 s = vsub(co, V3(p0.x, p0.y, p0.z));
+                        const float u = f * vdot(s, h);
+                        if (!((u > 0.0f) & (u < 1.0f))) continue;
+                        const v3 qq = vcross(s, edge_1);
+                        const float v = f * vdot(cd, qq);
+                        if (!((v > 0.0f) & ((u + v) < 1.0f))) continue;
+                        const float t = f * vdot(edge_2, qq);
+                        if (!((t > RAY_EPSILON) & (t < tcur))) continue;
+                        if (ANY) { q.socc[out_slot] = 1u; has_ray = false; break; }
+                        tcur = t; best_u = u; best_v = v; best_tri = i; best_prim = PRIM_TRI | cur_inst;
+                    }
+                } else {
+                    // TLAS leaf: instances are entered in order first .. first+count-1 (TopLevelBVH.cpp:71-75)
+                    for (int i = first + cnt - 1; i >= first; i--) push(~i);
+                }
+            } else {
+                // BVHNode::should_visit_left_first, BVHNode.h:30-40
+                bool left_first = true;
+                if (sc.traversal_strategy == RTX_TRAVERSE_ORDERED) {
+                    const int axis = (int)((uint32_t)cnt >> 30);
+                    if (axis == 1) left_first = cd.x > 0.0f;
+                    else if (axis == 2) left_first = cd.y > 0.0f;
+                    else if (axis == 3) left_first = cd.z > 0.0f;
+                }
+                if (left_first) { push(first + 1); push(first); }
+                else            { push(first); push(first + 1); }
+            }
+        }
+    }
+
+    if (n_stackerr) atomicOr(&ctr->error_flags, ERR_STACK_OVERFLOW);
+    if (COUNT) {
+        // wave reduction, one atomic per counter per wave
+        for (int off = 32; off > 0; off >>= 1) {
+            n_tlas += __shfl_down(n_tlas, off); n_blas += __shfl_down(n_blas, off);
+            n_inst += __shfl_down(n_inst, off); n_tri  += __shfl_down(n_tri, off);
+            n_rays += __shfl_down(n_rays, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&ctr->work[ANY ? W_TLAS_A : W_TLAS_C], (unsigned long long)n_tlas);
+            atomicAdd(&ctr->work[ANY ? W_BLAS_A : W_BLAS_C], (unsigned long long)n_blas);
+            atomicAdd(&ctr->work[ANY ? W_INST_A : W_INST_C], (unsigned long long)n_inst);
+            atomicAdd(&ctr->work[ANY ? W_TRI_A  : W_TRI_C],  (unsigned long long)n_tri);
+            atomicAdd(&ctr->work[ANY ? W_ANY_RAYS : W_CLOSEST_RAYS], (unsigned long long)n_rays);
+        }
+    }
+}

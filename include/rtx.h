@@ -280,6 +280,16 @@ int rtx_framebuffer_device_ptrs(rtx_ctx * ctx, void ** rgb_f32_dev, void ** pack
 int rtx_last_kernel_times(rtx_ctx * ctx, const char ** names, float * ms, int32_t capacity, int32_t * count);
 int rtx_enable_kernel_timing(rtx_ctx * ctx, int32_t enable);
 
+/* ---- unit-level entry points: one reference function each, evaluated on the device -------------
+ * (used by the parity tests; not needed by a renderer)                                          */
+
+/* fn: 0 acosf(a) 1 atan2f(a,b) 2 expf(a) 3 log2f(a) 4 atanf(a) 5 Util::float_to_int(a) 6 1/sqrtf(a) */
+int rtx_debug_libm(rtx_ctx * ctx, int32_t fn, const float * a, const float * b, float * out, int32_t n);
+/* Texture::sample (Texture.h:33-49) of an uploaded texture at n inputs (s,t,ds_dx,ds_dy,dt_dx,dt_dy) */
+int rtx_debug_texture_sample(rtx_ctx * ctx, int32_t texture_id, const float * in6, float * out_rgb, int32_t n);
+/* Sky::sample (Sky.cpp:28-68) of the uploaded sky at n directions */
+int rtx_debug_sky_sample(rtx_ctx * ctx, const float * directions_xyz, float * out_rgb, int32_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,113 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the oracle and the
+committed golden vectors produced by the real reference (tests/golden, see
+oracle/ref_harness/make_goldens.py).
+
+Tolerance: BASELINE.json states per-pixel RGB max-abs error < 1e-4.  The design goal is stricter:
+every discrete decision (hit/miss, shadow, texel index, mip level) is bit-identical, so frames are
+expected to be BIT-EXACT except where expf (Beer, Raytracer.cpp:370-372) or log2f (mip LOD) enter,
+where the device evaluates in fp64 and the host libm is within 1 ulp of that.
+"""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def api():
+    from pyrtx import api as a
+    a.load_library()
+    return a
+
+
+@pytest.mark.parametrize("name", list(util.GOLDENS))
+def test_frame_matches_reference_golden(api, name):
+    sc, g = util.load_golden(name)
+    out = api.Renderer(sc).render()
+    cmp = util.compare_to_golden(out, g)
+    assert cmp["stats_equal"], (out["stats"], g["stats"])
+    assert cmp["nan_mismatch"] == 0
+    assert cmp["max_abs"] < TOL, cmp
+    assert cmp["packed_mismatch"] == 0, cmp
+
+
+@pytest.mark.parametrize("name", ["cube", "monkey_small", "materials_aniso", "dynamic", "tori16"])
+def test_frame_matches_oracle_and_work_counters(api, name):
+    import orc
+    sc, g = util.load_golden(name)
+    out = api.Renderer(sc).render(count_work=True)
+    ref = orc.OracleScene(sc).render(threads=8)
+    assert out["stats"] == ref["stats"]
+    d = np.abs(out["rgb"].astype(np.float64) - ref["rgb"].astype(np.float64))
+    assert np.nanmax(d) < TOL
+    assert np.array_equal(out["packed"], ref["packed"])
+    # the roofline accounting relies on these agreeing exactly with the CPU restatement
+    for k in ("closest_rays", "any_rays", "tlas_nodes_closest", "tlas_nodes_any", "blas_nodes_closest", "blas_nodes_any",
+              "instances_closest", "instances_any", "tri_tests_closest", "tri_tests_any", "shaded_hits", "sky_lookups",
+              "texel_fetches", "rays_spawned"):
+        assert out["work"][k] == ref["work"][k], (k, out["work"][k], ref["work"][k])
+
+
+def test_scenes_without_transcendentals_are_bit_exact(api):
+    for name in ("cube", "monkey_small"):
+        sc, g = util.load_golden(name)
+        out = api.Renderer(sc).render()
+        assert np.array_equal(out["rgb"].view(np.uint32), g["rgb"].view(np.uint32)), name
+
+
+def test_tile_subsets_and_strides(api):
+    """Round-robin tile shards (the multi-GPU partition) reproduce the full frame."""
+    sc, g = util.load_golden("materials_aniso")
+    full = api.Renderer(sc).render()
+    r = api.Renderer(sc)
+    for shard in range(3):
+        n = (sc.tile_count - shard + 2) // 3
+        r.render_async(first_tile=shard, tile_stride=3, tile_count=n)
+    rgb, packed = r.framebuffer()
+    assert np.array_equal(rgb.view(np.uint32), full["rgb"].view(np.uint32))
+    assert np.array_equal(packed, full["packed"])
+    # a single tile only touches its own pixels
+    r2 = api.Renderer(sc)
+    r2.render_async(first_tile=5, tile_stride=1, tile_count=1)
+    rgb2, _ = r2.framebuffer()
+    ty, tx = (5 // sc.tile_count_x) * 32, (5 % sc.tile_count_x) * 32
+    mask = np.zeros((sc.height, sc.width), bool); mask[ty:ty + 32, tx:tx + 32] = True
+    assert np.all(rgb2[~mask] == 0)
+    assert np.array_equal(rgb2[mask].view(np.uint32), full["rgb"][mask].view(np.uint32))
+
+
+def test_empty_and_invalid_inputs(api):
+    sc, _ = util.load_golden("cube")
+    r = api.Renderer(sc)
+    r.render_async(first_tile=0, tile_stride=1, tile_count=0)          # empty batch is legal
+    st, _ = r.stats()
+    assert st == {"primary": 0, "shadow": 0, "reflection": 0, "refraction": 0}
+    with pytest.raises(api.RtxError):
+        r.render_async(first_tile=sc.tile_count, tile_stride=1, tile_count=1)   # out of range tile
+    with pytest.raises(api.RtxError):
+        r.render_async(first_tile=0, tile_stride=0, tile_count=1)
+    # render before set_frame
+    r3 = api.Renderer(sc, upload=False)
+    with pytest.raises(api.RtxError) as e:
+        r3.render_async()
+    assert e.value.code == 5
+    # MAX_MATERIALS (Config.h:18)
+    import ctypes as C
+    mats = np.zeros(257, util.sio.MATERIAL)
+    assert r3.lib.rtx_upload_materials(r3.ctx, mats.ctypes.data, 257) == 4
+
+
+def test_ragged_resolution(api):
+    """Width/height not multiples of 32: edge tiles are clipped (WorkerThread.cpp:60-61)."""
+    import orc
+    sc, _ = util.load_golden("monkey_small")
+    sc.config["width"] = 301; sc.config["height"] = 173
+    # camera basis depends on the resolution (Camera.cpp:5-16): rebuild top-left for identity-free scenes is not needed
+    out = api.Renderer(sc).render()
+    ref = orc.OracleScene(sc).render(threads=8)
+    assert np.array_equal(out["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+    assert out["stats"] == ref["stats"]
