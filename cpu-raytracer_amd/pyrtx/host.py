@@ -1,0 +1,279 @@
+"""ctypes binding of librtx_host.so (include/rtx_host.h) and scene construction on top of it.
+
+Host-side only: per-frame Scene::update equivalents, this repo's own BLAS builder, the procedural
+cfg3 "atrium" stand-in for the absent Sponza mesh.  Produces pyrtx.scene_io.Scene objects, which
+both the product (api.Renderer) and the oracle consume as plain data.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import scene_io as sio
+from .ctypes_structs import RtxCamera, RtxTextureDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "host", "librtx_host.so")
+EXPORTS = ["rtxh_camera_basis", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
+           "rtxh_tlas_build", "rtxh_blas_build", "rtxh_texture_mips", "rtxh_atrium_generate", "rtxh_mesh_free"]
+
+PI = np.float32(3.14159265359)          # Util.h:8
+
+
+class RtxhMesh(C.Structure):
+    _fields_ = [("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)), ("texcoords", C.POINTER(C.c_float)),
+                ("material_ids", C.POINTER(C.c_int32)), ("triangle_count", C.c_int32), ("material_count", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.abspath(LIB_PATH)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: run __graft_entry__.build()")
+        l = C.CDLL(path)
+        vp, i32 = C.c_void_p, C.c_int32
+        l.rtxh_camera_basis.argtypes = [i32, i32, C.c_float, vp, vp, C.POINTER(RtxCamera)]
+        l.rtxh_instance_update.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        l.rtxh_plane_update.argtypes = [vp, vp, i32, vp]
+        l.rtxh_tlas_create.argtypes = [i32, C.POINTER(vp)]
+        l.rtxh_tlas_destroy.argtypes = [vp]
+        l.rtxh_tlas_build.argtypes = [vp, vp, vp, vp, vp, C.POINTER(i32)]
+        l.rtxh_blas_build.argtypes = [vp, i32, i32, vp, C.POINTER(i32), vp]
+        l.rtxh_texture_mips.argtypes = [vp, i32, i32, C.POINTER(RtxTextureDesc), C.POINTER(C.c_int64)]
+        l.rtxh_atrium_generate.argtypes = [C.c_uint32, i32, C.POINTER(RtxhMesh)]
+        l.rtxh_mesh_free.argtypes = [C.POINTER(RtxhMesh)]
+        for n in EXPORTS:
+            getattr(l, n).restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def axis_angle(axis: Sequence[float], angle: float) -> np.ndarray:
+    """Quaternion::axis_angle, Quaternion.h:24-34 (sinf/cosf in fp32)."""
+    half = np.float32(0.5) * np.float32(angle)
+    s = np.float32(math.sin(float(half)))   # libm sinf == correctly rounded double sin for all but rare cases; data only
+    s = np.sin(half, dtype=np.float32)
+    c = np.cos(half, dtype=np.float32)
+    a = _f32(axis)
+    return np.array([a[0] * s, a[1] * s, a[2] * s, c], np.float32)
+
+
+def camera_basis(width: int, height: int, fov: float, position, rotation) -> np.ndarray:
+    out = RtxCamera()
+    p, r = _f32(position), _f32(rotation)
+    rc = lib().rtxh_camera_basis(width, height, C.c_float(fov), p.ctypes.data, r.ctypes.data, C.byref(out))
+    assert rc == 0
+    cam = np.zeros(1, sio.CAMERA)
+    C.memmove(cam.ctypes.data, C.byref(out), C.sizeof(out))
+    return cam
+
+
+def instance_update(position, rotation, root_min, root_max, blas_id: int):
+    inst = np.zeros(1, sio.INSTANCE)
+    mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    p, r, a, b = _f32(position), _f32(rotation), _f32(root_min), _f32(root_max)
+    rc = lib().rtxh_instance_update(p.ctypes.data, r.ctypes.data, a.ctypes.data, b.ctypes.data, inst.ctypes.data, mn.ctypes.data, mx.ctypes.data)
+    assert rc == 0
+    inst["blas_id"] = blas_id
+    return inst, mn, mx
+
+
+def plane_update(position, rotation, material_id: int) -> np.ndarray:
+    out = np.zeros(1, sio.PLANE)
+    p, r = _f32(position), _f32(rotation)
+    assert lib().rtxh_plane_update(p.ctypes.data, r.ctypes.data, material_id, out.ctypes.data) == 0
+    return out
+
+
+class Tlas:
+    """Persistent TLAS builder: TopLevelBVH::init + build_bvh every frame (TopLevelBVH.cpp:5-45)."""
+
+    def __init__(self, n: int):
+        self.n = n
+        self.h = C.c_void_p()
+        assert lib().rtxh_tlas_create(n, C.byref(self.h)) == 0
+
+    def build(self, positions: np.ndarray, aabbs: np.ndarray):
+        p, a = _f32(positions).reshape(self.n, 3), _f32(aabbs).reshape(self.n, 6)
+        nodes = np.zeros(2 * self.n, sio.BVH_NODE)
+        idx = np.zeros(self.n, np.int32)
+        nc = C.c_int32()
+        assert lib().rtxh_tlas_build(self.h, p.ctypes.data, a.ctypes.data, nodes.ctypes.data, idx.ctypes.data, C.byref(nc)) == 0
+        return nodes[:nc.value].copy(), idx
+
+    def __del__(self):
+        try:
+            lib().rtxh_tlas_destroy(self.h)
+        except Exception:
+            pass
+
+
+def build_blas(positions: np.ndarray, normals: np.ndarray, texcoords: np.ndarray, material_ids: np.ndarray,
+               material_offset: int, bins: int = 32) -> sio.Blas:
+    """Triangle soup (n,3,3) + per-vertex normals (n,3,3) + texcoords (n,3,2) -> flattened BLAS
+    (TriangleHot / TriangleCold as OBJLoader.cpp:156-175 fills them)."""
+    pos = _f32(positions).reshape(-1, 9)
+    n = pos.shape[0]
+    nodes = np.zeros(2 * n, sio.BVH_NODE)
+    order = np.zeros(n, np.int32)
+    nc = C.c_int32()
+    rc = lib().rtxh_blas_build(pos.ctypes.data, n, bins, nodes.ctypes.data, C.byref(nc), order.ctypes.data)
+    assert rc == 0, rc
+    p = pos.reshape(n, 3, 3)[order]
+    nr = _f32(normals).reshape(n, 3, 3)[order]
+    uv = _f32(texcoords).reshape(n, 3, 2)[order]
+    hot = np.zeros(n, sio.TRI_HOT)
+    hot["position_0"] = p[:, 0]; hot["position_edge_1"] = p[:, 1] - p[:, 0]; hot["position_edge_2"] = p[:, 2] - p[:, 0]
+    cold = np.zeros(n, sio.TRI_COLD)
+    cold["tex_coord_0"] = uv[:, 0]; cold["tex_coord_edge_1"] = uv[:, 1] - uv[:, 0]; cold["tex_coord_edge_2"] = uv[:, 2] - uv[:, 0]
+    cold["normal_0"] = nr[:, 0]; cold["normal_edge_1"] = nr[:, 1] - nr[:, 0]; cold["normal_edge_2"] = nr[:, 2] - nr[:, 0]
+    cold["material_id"] = np.asarray(material_ids, np.int32)[order]
+    return sio.Blas(nodes[:nc.value].copy(), hot, cold, material_offset, n)
+
+
+def texture_with_mips(level0_rgb: np.ndarray) -> sio.Texture:
+    """level0_rgb: (h, w, 3) linear-space float32 -> Texture with the reference's box-filter chain."""
+    h, w, _ = level0_rgb.shape
+    buf = np.zeros((w * h + (w * h) // 3 + 2, 3), np.float32)
+    buf[:w * h] = level0_rgb.reshape(-1, 3)
+    desc = RtxTextureDesc()
+    cnt = C.c_int64()
+    assert lib().rtxh_texture_mips(buf.ctypes.data, w, h, C.byref(desc), C.byref(cnt)) == 0
+    d = np.zeros(1, sio.TEXTURE_DESC)
+    C.memmove(d.ctypes.data, C.byref(desc), C.sizeof(desc))
+    return sio.Texture(d, buf[:cnt.value].copy())
+
+
+def gamma_to_linear(x: np.ndarray) -> np.ndarray:
+    """Math::gamma_to_linear, Math.h:78-88 (used by Texture::load, Texture.cpp:64-72)."""
+    x = np.asarray(x, np.float32)
+    lin = np.where(x < np.float32(0.04045), x / np.float32(12.92), np.power((x + np.float32(0.055)) / np.float32(1.055), np.float32(2.4), dtype=np.float32))
+    return np.clip(np.where(x <= 0, 0, np.where(x >= 1, 1, lin)), 0, 1).astype(np.float32)
+
+
+def synthetic_sky(n: int = 64) -> np.ndarray:
+    """Seeded stand-in for Data/Sky_Probes/rnl_probe.float (absent from the reference mount);
+    identical to the probe the golden vectors were rendered with (oracle/ref_harness/make_goldens.py)."""
+    y, x = np.mgrid[0:n, 0:n]
+    sky = np.zeros((n, n, 3), np.float32)
+    sky[..., 0] = 0.5 + 0.5 * x / n
+    sky[..., 1] = 0.6 + 0.2 * (((x // 8) + (y // 8)) & 1)
+    sky[..., 2] = 0.5 + 0.5 * y / n
+    return sky
+
+
+def _procedural_textures(seed: int) -> List[sio.Texture]:
+    rng = np.random.RandomState(seed & 0x7fffffff)
+
+    def noise(n, octaves=4):
+        out = np.zeros((n, n), np.float32)
+        for o in range(octaves):
+            k = 2 ** (o + 2)
+            g = rng.rand(k, k).astype(np.float32)
+            out += np.kron(g, np.ones((n // k, n // k), np.float32)) / (2 ** o)
+        return out / out.max()
+
+    texs = []
+    n = 256   # floor tiles
+    y, x = np.mgrid[0:n, 0:n]
+    tile = (((x // 32) + (y // 32)) & 1).astype(np.float32)
+    grout = ((x % 32 < 2) | (y % 32 < 2)).astype(np.float32)
+    base = 0.55 + 0.25 * tile - 0.3 * grout + 0.1 * noise(n)
+    texs.append(np.stack([base, base * 0.95, base * 0.85], -1))
+    n = 512   # bricks
+    y, x = np.mgrid[0:n, 0:n]
+    row = y // 32
+    xs = (x + (row & 1) * 32) % 64
+    mortar = ((xs < 3) | (y % 32 < 3)).astype(np.float32)
+    nb = noise(n)
+    texs.append(np.stack([0.62 - 0.35 * mortar + 0.15 * nb, 0.34 - 0.1 * mortar + 0.1 * nb, 0.27 - 0.05 * mortar + 0.08 * nb], -1))
+    n = 256   # stone
+    s = 0.45 + 0.4 * noise(n, 5)
+    texs.append(np.stack([s, s * 0.97, s * 0.9], -1))
+    n = 256   # fabric stripes
+    y, x = np.mgrid[0:n, 0:n]
+    f = 0.6 + 0.3 * np.sin(x * (2 * np.pi / 16)).astype(np.float32) + 0.08 * noise(n)
+    texs.append(np.stack([f, f, f], -1))
+    return [texture_with_mips(gamma_to_linear(np.clip(t, 0, 1).astype(np.float32))) for t in texs]
+
+
+def make_config(width, height, bounces, mip_filter=1, texture_mode=2, stack_size=64, traversal=1, max_aniso=8.0) -> np.ndarray:
+    cfg = np.zeros(1, sio.CONFIG)
+    cfg["width"] = width; cfg["height"] = height; cfg["bounces"] = bounces; cfg["stack_size"] = stack_size
+    cfg["traversal_strategy"] = traversal; cfg["texture_mode"] = texture_mode; cfg["mip_filter"] = mip_filter
+    cfg["max_anisotropy"] = max_aniso
+    return cfg
+
+
+def atrium_scene(width: int = 1920, height: int = 1080, bounces: int = 3, detail: int = 4, seed: int = 0x5EED0003,
+                 mip_filter: int = 1, bins: int = 32) -> sio.Scene:
+    """BASELINE.json configs[2]: Sponza-class (~265k triangles at detail 4) stand-in, 3 lights,
+    reflect/refract depth 3, anisotropic mip filter (the shipped default, Config.h:53)."""
+    mesh = RtxhMesh()
+    assert lib().rtxh_atrium_generate(seed, detail, C.byref(mesh)) == 0
+    n = mesh.triangle_count
+    pos = np.ctypeslib.as_array(mesh.positions, (n, 3, 3)).copy()
+    nrm = np.ctypeslib.as_array(mesh.normals, (n, 3, 3)).copy()
+    uv = np.ctypeslib.as_array(mesh.texcoords, (n, 3, 2)).copy()
+    mid = np.ctypeslib.as_array(mesh.material_ids, (n,)).copy()
+    nmat = mesh.material_count
+    lib().rtxh_mesh_free(C.byref(mesh))
+
+    sc = sio.Scene()
+    sc.config = make_config(width, height, bounces, mip_filter=mip_filter)
+    sc.textures = _procedural_textures(seed)
+    # material table: 0 = MaterialBuffer default (Material.h:52-60), then the mesh's materials (sponza.mtl-like Kd ~0.47)
+    mats = np.zeros(1 + nmat, sio.MATERIAL)
+    mats["texture_id"] = -1; mats["index_of_refraction"] = 1.0
+    m = mats[1:]
+    m["diffuse"] = 0.4704
+    kd = {0: (0.75, 0.75, 0.75), 1: (0.8, 0.8, 0.8), 2: (0.7, 0.68, 0.6), 3: (0.8, 0.78, 0.74), 4: (0.6, 0.58, 0.5), 5: (0.75, 0.73, 0.7), 6: (0.5, 0.47, 0.4)}
+    for k, v in kd.items():
+        m["diffuse"][k] = v
+    tex = {0: 0, 1: 1, 2: 1, 3: 2, 4: 2, 5: 2, 6: 2}
+    for k, v in tex.items():
+        m["texture_id"][k] = v
+    m["reflection"][0] = (0.15, 0.15, 0.15)                       # polished floor
+    curtain = [(0.7, 0.1, 0.1), (0.1, 0.5, 0.15), (0.1, 0.15, 0.7), (0.7, 0.6, 0.1), (0.6, 0.1, 0.6), (0.1, 0.6, 0.6)]
+    for i, c in enumerate(curtain):
+        m["diffuse"][7 + i] = c; m["texture_id"][7 + i] = 3
+    # vases: glass, metal, tinted glass, dark metal
+    m["diffuse"][13] = (0.05, 0.05, 0.05); m["reflection"][13] = (0.25, 0.25, 0.25); m["transmittance"][13] = (0.95, 0.95, 0.95); m["index_of_refraction"][13] = 1.5
+    m["diffuse"][14] = (0.3, 0.25, 0.1); m["reflection"][14] = (0.8, 0.7, 0.4)
+    m["diffuse"][15] = (0.05, 0.1, 0.05); m["reflection"][15] = (0.2, 0.2, 0.2); m["transmittance"][15] = (0.6, 0.9, 0.7); m["index_of_refraction"][15] = 1.33
+    m["diffuse"][16] = (0.1, 0.1, 0.12); m["reflection"][16] = (0.6, 0.6, 0.65)
+    for i in range(4):                                               # statues: bronze-ish
+        m["diffuse"][17 + i] = (0.45 - 0.05 * i, 0.3, 0.15 + 0.04 * i); m["reflection"][17 + i] = (0.12, 0.1, 0.06)
+    m["diffuse"][21] = (0.35, 0.3, 0.25); m["diffuse"][22] = (0.6, 0.6, 0.6); m["diffuse"][23] = (0.85, 0.85, 0.8); m["diffuse"][24] = (0.5, 0.5, 0.5)
+    sc.materials = mats
+    sc.blas = [build_blas(pos, nrm, uv, mid, material_offset=1, bins=bins)]
+    root = sc.blas[0].nodes[0]
+    inst, mn, mx = instance_update((0, 0, 0), (0, 0, 0, 1), root["aabb_min"], root["aabb_max"], 0)
+    sc.instances = inst
+    tl = Tlas(1)
+    sc.tlas_nodes, sc.tlas_indices = tl.build(np.zeros((1, 3), np.float32), np.concatenate([mn, mx])[None])
+    sc.sky = synthetic_sky()
+    # 3 lights: the shipped directional light (Scene.cpp:125), one point, one spot
+    d = np.array([0.1, -1.0, 0.1], np.float32); d = d / np.sqrt((d * d).sum(dtype=np.float32), dtype=np.float32)
+    sc.dir_lights = np.zeros(1, sio.DIR_LIGHT); sc.dir_lights["colour"] = 0.9; sc.dir_lights["negative_direction"] = -d
+    sc.point_lights = np.zeros(1, sio.POINT_LIGHT); sc.point_lights["colour"] = (30.0, 26.0, 20.0); sc.point_lights["position"] = (-6.0, 9.0, 0.5)
+    sd = np.array([-0.8, -0.55, 0.25], np.float32); sd = sd / np.sqrt((sd * sd).sum(dtype=np.float32), dtype=np.float32)
+    sc.spot_lights = np.zeros(1, sio.SPOT_LIGHT); sc.spot_lights["colour"] = (40.0, 40.0, 48.0); sc.spot_lights["position"] = (20.0, 14.0, -2.0)
+    sc.spot_lights["negative_direction"] = -sd
+    sc.spot_lights["inner_cutoff"] = np.cos(np.float32(0.5 * 50.0) * PI * np.float32(0.00555555555), dtype=np.float32)   # DEG_TO_RAD, Util.h:14
+    sc.spot_lights["outer_cutoff"] = np.cos(np.float32(0.5 * 70.0) * PI * np.float32(0.00555555555), dtype=np.float32)
+    fov = float(np.float32(110.0) * PI * np.float32(0.00555555555))                                                       # Scene.cpp:75
+    sc.camera = camera_basis(width, height, fov, (24.0, 5.5, 1.2), axis_angle((0, 1, 0), -1.45))
+    return sc

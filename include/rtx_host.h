@@ -1,0 +1,75 @@
+/*
+ * rtx_host.h — C ABI of librtx_host.so: the host-side callers of the render path.
+ *
+ * CPU-only code that prepares what include/rtx.h consumes, i.e. the reference's per-frame
+ * Scene::update (Scene.cpp:139-171) and its load-time BottomLevelBVH construction.  Nothing here
+ * runs on the GPU and nothing here renders; the render path itself is librtx_hip.so.
+ *
+ *   rtxh_camera_basis        Camera::resize + Camera::update basis       Camera.cpp:5-16,44-47
+ *   rtxh_instance_update     Mesh::update                                 Mesh.cpp:9-15
+ *                            (Transform::calc_world_matrix Transform.h:13-43, AABB::transform
+ *                             AABB.cpp:55-73, Matrix4::invert Matrix4.h:88-138)
+ *   rtxh_plane_update        Plane::update                                Plane.cpp:3-11
+ *   rtxh_tlas_*              TopLevelBVH::init / build_bvh                TopLevelBVH.cpp:5-45
+ *                            (BVHBuilders::build_bvh<Mesh> BVHBuilders.h:8-46,
+ *                             BVHPartitions::{calculate_bounds,partition_sah,split_indices})
+ *   rtxh_blas_build          a BottomLevelBVH for a triangle soup: this repo's OWN binned-SAH
+ *                            builder (not the reference's SBVH), output in the
+ *                            reference's node convention + flattened leaf order
+ *                            (BVHNode.h:10-28, BottomLevelBVH.cpp:196-212)
+ *   rtxh_texture_mips        Texture::load's box-filter mip chain          Texture.cpp:76-117
+ *   rtxh_atrium_*            seeded procedural stand-in for the absent Sponza mesh
+ */
+#ifndef RTX_HOST_H
+#define RTX_HOST_H
+
+#include <stdint.h>
+#include "rtx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* position[3], rotation quaternion (x,y,z,w), fov in radians -> rtx_camera */
+int rtxh_camera_basis(int32_t width, int32_t height, float fov, const float position[3], const float rotation[4], rtx_camera * out);
+
+/* Mesh::update: fills out->world / world_inv (blas_id untouched) and the world-space AABB of the instance */
+int rtxh_instance_update(const float position[3], const float rotation[4], const float blas_root_min[3], const float blas_root_max[3],
+                         rtx_instance * out, float out_aabb_min[3], float out_aabb_max[3]);
+
+int rtxh_plane_update(const float position[3], const float rotation[4], int32_t material_id, rtx_plane * out);
+
+/* Persistent TLAS builder (keeps the three index arrays across frames like TopLevelBVH does). */
+typedef struct rtxh_tlas rtxh_tlas;
+int rtxh_tlas_create(int32_t instance_count, rtxh_tlas ** out);
+int rtxh_tlas_destroy(rtxh_tlas * t);
+/* positions: n*3 (Mesh::get_position = transform.position), aabbs: n*6 (min,max).  nodes_out holds
+ * 2*n entries, indices_out n entries; *node_count_out receives TopLevelBVH::node_count.          */
+int rtxh_tlas_build(rtxh_tlas * t, const float * positions, const float * aabbs,
+                    rtx_bvh_node * nodes_out, int32_t * indices_out, int32_t * node_count_out);
+
+/* Triangle soup -> flattened BLAS.  positions: n*9 floats (p0,p1,p2).  nodes_out must hold 2*n
+ * entries, order_out n entries: order_out[k] = source triangle stored at flattened slot k.       */
+int rtxh_blas_build(const float * positions, int32_t triangle_count, int32_t bins,
+                    rtx_bvh_node * nodes_out, int32_t * node_count_out, int32_t * order_out);
+
+/* Appends the box-filter mip chain to level 0 (texels_rgb holds w*h float3 on entry and must have
+ * room for w*h + w*h/3 + 1 texels); fills desc like Texture::load.                               */
+int rtxh_texture_mips(float * texels_rgb, int32_t width, int32_t height, rtx_texture_desc * desc, int64_t * texel_count_out);
+
+/* Procedural "atrium": returns the triangle count for a detail level, then fills caller arrays.   */
+typedef struct rtxh_mesh {
+    float *   positions;     /* n*9  */
+    float *   normals;       /* n*9  */
+    float *   texcoords;     /* n*6  (already in the reference's convention: v flipped, OBJLoader.cpp:139-141) */
+    int32_t * material_ids;  /* n    (mesh-local) */
+    int32_t   triangle_count;
+    int32_t   material_count;
+} rtxh_mesh;
+int rtxh_atrium_generate(uint32_t seed, int32_t detail, rtxh_mesh * out);   /* allocates; free with rtxh_mesh_free */
+int rtxh_mesh_free(rtxh_mesh * m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
