@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the render path on MI355X.
+
+Metric (BASELINE.json): Mrays/s (primary + shadow + reflection + refraction, counted exactly as the
+reference's PerformanceStats at SIMD_LANE_SIZE 1) and ms/frame, "Sponza 1920x1080" at 1/2/4/8 GPUs.
+Sponza itself is absent from the reference mount, so the workload is the seeded Sponza-class
+stand-in of SURVEY.md 8(d) ("atrium": 255 296 triangles, 25 materials, 3 lights, depth 3,
+anisotropic mip filter).
+
+A "step" is one full frame: rtx_render_tiles over this rank's tiles (inputs resident in HBM) and,
+for N > 1, the RCCL gather of the packed framebuffer tiles to rank 0 (BASELINE configs[3]); the frame
+is fixed as N grows, so scaling is "strong".  Launch: `python bench.py --gpus N --steps K --warmup W`;
+for N > 1 through torch.distributed.run (one process per GPU).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "cpu-raytracer_amd"))
+
+import numpy as np  # noqa: E402
+
+
+def algorithmic_bytes_closest(work, level0_rays):
+    """Algorithmic bytes moved by all k_trace<closest> launches of one frame:
+    32 B per BVH node popped (BVHNode.h:10), 64 B inverse matrix per instance entered (Mesh.h:10),
+    36 B TriangleHot per triangle test (BottomLevelBVH.h:6-10), 24 B origin+direction read per queued
+    ray (primary rays are generated, not read), 20 B hit record written per ray."""
+    rays = work["closest_rays"]
+    return (32 * (work["tlas_nodes_closest"] + work["blas_nodes_closest"]) + 64 * work["instances_closest"]
+            + 36 * work["tri_tests_closest"] + 24 * max(rays - level0_rays, 0) + 20 * rays)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="atrium", choices=["atrium", "monkey", "tori16", "materials"])
+    ap.add_argument("--detail", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget (0 disables)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+    from pyrtx import api, host
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback for the render path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- scene (built on the host by this repo's own tools; identical on every rank) ----------------
+    if args.workload == "atrium":
+        sc = host.atrium_scene(args.width, args.height, bounces=3, detail=args.detail)
+        workload = (f"atrium-{sc.triangle_refs()}tri Sponza-class stand-in (sponza.obj absent from the reference mount) "
+                    f"{args.width}x{args.height}, 3 lights, reflect/refract depth 3, anisotropic mips")
+    else:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import util
+        name = {"monkey": "monkey", "tori16": "tori16", "materials": "materials_aniso"}[args.workload]
+        sc, _ = util.load_golden(name)
+        workload = f"{name} golden scene {sc.width}x{sc.height}"
+
+    r = api.Renderer(sc, device=local_rank)
+    W, H = sc.width, sc.height
+    fb_rgb = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    fb_packed = torch.zeros(H * W, dtype=torch.int32, device="cuda")
+    r.bind_framebuffer(fb_rgb.data_ptr(), fb_packed.data_ptr())
+    stream = torch.cuda.current_stream()
+    r.set_stream(stream.cuda_stream)
+
+    T = sc.tile_count
+    first, stride = rank, world                                  # tile t belongs to GPU t mod N
+    count = (T - rank + world - 1) // world if rank < T else 0
+
+    # ---- gather plumbing (N > 1): each rank sends only the pixels of its own tiles ---------------------
+    if world > 1:
+        tcx = sc.tile_count_x
+        per_rank = (T + world - 1) // world
+
+        def tile_pixels(rk):
+            idx = np.full((per_rank, 32, 32), -1, np.int64)
+            for k, t in enumerate(range(rk, T, world)):
+                ty, tx = (t // tcx) * 32, (t % tcx) * 32
+                ys, xs = np.mgrid[ty:ty + 32, tx:tx + 32]
+                ok = (ys < H) & (xs < W)
+                idx[k] = np.where(ok, ys * W + xs, -1)
+            return idx.reshape(-1)
+        my_idx_np = tile_pixels(rank)
+        my_idx = torch.from_numpy(np.where(my_idx_np >= 0, my_idx_np, 0)).cuda()
+        send = torch.zeros(per_rank * 1024, dtype=torch.int32, device="cuda")
+        if rank == 0:
+            recv = [torch.zeros_like(send) for _ in range(world)]
+            all_idx = [tile_pixels(rk) for rk in range(world)]
+            valid = [torch.from_numpy(np.nonzero(a >= 0)[0]).cuda() for a in all_idx]
+            dest = [torch.from_numpy(a[a >= 0]).cuda() for a in all_idx]
+            final = torch.zeros(H * W, dtype=torch.int32, device="cuda")
+
+    def step():
+        r.render_async(first, stride, count)
+        if world > 1:
+            torch.index_select(fb_packed, 0, my_idx, out=send)
+            dist.gather(send, recv if rank == 0 else None, dst=0)
+            if rank == 0:                                           # un-swizzle tile-major -> raster on the root
+                for rk in range(world):
+                    final.index_copy_(0, dest[rk], recv[rk].index_select(0, valid[rk]))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # ---- untimed: ray counts and work counters of one frame -----------------------------------------------
+    r.render_async(first, stride, count, count_work=True)
+    stats, work = r.stats()
+    rays_rank = sum(stats.values())
+    tot = torch.tensor([stats["primary"], stats["shadow"], stats["reflection"], stats["refraction"], rays_rank], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot)
+    tot = tot.cpu().tolist()
+    level0_rays = stats["primary"]
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    r.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    t1 = time.perf_counter()
+    ktimes = r.kernel_times()
+    r.enable_timing(False)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
+
+    if rank == 0:
+        mrays = tot[4] / (ms_per_step * 1e-3) * 1e-6
+        by_kernel = {}
+        for name, ms in ktimes:
+            by_kernel.setdefault(name, []).append(ms)
+        kern = {k: {"launches": len(v), "avg_ms": float(np.mean(v)), "total_ms_per_step": float(np.sum(v)) / max(args.steps, 1)} for k, v in by_kernel.items()}
+        dom = "k_trace_closest"
+        bytes_frame = algorithmic_bytes_closest(work, level0_rays)
+        launches_per_frame = len(by_kernel.get(dom, [])) / max(args.steps, 1)
+        avg_s = kern[dom]["avg_ms"] * 1e-3 if dom in kern else float("nan")
+        achieved = (bytes_frame / max(launches_per_frame, 1)) / avg_s / 1e9 if dom in kern else None
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom + "_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (primary+shadow+reflection+refraction)", "value": round(mrays, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "width": W, "height": H, "bounces": int(sc.config["bounces"][0]),
+                       "triangles": sc.triangle_refs(), "bvh_nodes": int(sum(len(b.nodes) for b in sc.blas)),
+                       "tiles": T, "sharding": "tile t -> GPU t mod N; RCCL gather of packed tiles to rank 0" if world > 1 else "single GPU"},
+            "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3], "total": tot[4]},
+            "mprimary_per_s": round(tot[0] / (ms_per_step * 1e-3) * 1e-6, 3),
+            "kernels": kern,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": None if achieved is None else round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": None if achieved is None else round(achieved / 8000.0, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(bytes_frame / max(launches_per_frame, 1)),
+                         "avg_launch_ms": None if dom not in kern else round(kern[dom]["avg_ms"], 5),
+                         "bytes_per_ray": round(bytes_frame / max(work["closest_rays"], 1), 1)},
+        }
+        # ---- CPU baseline: the oracle (port of the reference's lane-1 path) on this box's host cores ------
+        if world == 1 and args.cpu_seconds > 0:
+            sys.path.insert(0, os.path.join(REPO, "oracle"))
+            import orc
+            cores = os.cpu_count() or 1
+            o = orc.OracleScene(sc)
+            frames, t_cpu, ref = 0, 0.0, None
+            while t_cpu < args.cpu_seconds and frames < 50:
+                t = time.perf_counter()
+                ref = o.render(threads=cores)
+                t_cpu += time.perf_counter() - t
+                frames += 1
+            cpu_rays = sum(ref["stats"].values())
+            out["cpu_baseline"] = {"value": round(cpu_rays * frames / t_cpu * 1e-6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                                   "sample": f"{frames} full frame(s) of the same workload, oracle/rt_oracle.c (scalar lane-1 restatement), {cores} threads",
+                                   "ms_per_frame": round(1000.0 * t_cpu / frames, 2)}
+            rgb = fb_rgb.cpu().numpy().reshape(H, W, 3)
+            d = np.abs(rgb.astype(np.float64) - ref["rgb"].astype(np.float64))
+            out["parity"] = {"max_abs_rgb_vs_oracle": float(np.nanmax(d)), "pixels_differing": int((d.max(axis=-1) > 0).sum()),
+                             "packed_mismatch": int((fb_packed.cpu().numpy().view(np.uint32).reshape(H, W) != ref["packed"]).sum()),
+                             "stats_equal": ref["stats"] == stats}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,7 +35,9 @@ struct KernelTime { const char * name; hipEvent_t a, b; };
 
 struct rtx_ctx {
     rtx_config cfg;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // stream all work is enqueued on
+    hipStream_t own_stream = nullptr;    // created by rtx_create
+    void * ext_rgb = nullptr, * ext_packed = nullptr;
     std::string err;
     int n_cu = 0;
 
@@ -121,7 +123,8 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, config->device) != hipSuccess) { delete c; return RTX_ERR_HIP; }
     c->n_cu = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RTX_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RTX_ERR_HIP; }
+    c->stream = c->own_stream;
 
     // Texture::init(alpha = 2) EWA weight table, Texture.h:53-62 (host libm, like the reference; shipped as data)
     float ewa[RTX_EWA_LUT_SIZE];
@@ -173,7 +176,7 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     for (DevBuf & b : c->qb) if (b.p) hipFree(b.p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     for (DevCounters * h : c->pending_host) hipHostFree(h);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return RTX_OK;
 }
@@ -349,8 +352,8 @@ static int alloc_queues(rtx_ctx * c, int batch_tiles) {
     if (!rc) rc = ensure(c, c->qb[k], sslots * 4); c->q.socc = (uint32_t *)c->qb[k].p; k++;
     c->q.spill = (int32_t *)c->d_spill.p;
     c->q.counters = (DevCounters *)c->d_counters.p;
-    c->q.fb_rgb = (float *)c->d_fb_rgb.p;
-    c->q.fb_packed = (uint32_t *)c->d_fb_packed.p;
+    c->q.fb_rgb = (float *)(c->ext_rgb ? c->ext_rgb : c->d_fb_rgb.p);
+    c->q.fb_packed = (uint32_t *)(c->ext_packed ? c->ext_packed : c->d_fb_packed.p);
     return rc;
 }
 
@@ -386,7 +389,6 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
 
     // stats of this call: reset accumulators (WorkerThread.cpp:120 zeroes them per frame)
     HIP_OK(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), c->stream));
-    c->times.clear(); c->event_next = 0;
     if (tile_count == 0) { c->stats_pending = true; return RTX_OK; }
 
     int batch_tiles = 0;
@@ -457,21 +459,38 @@ extern "C" int rtx_read_framebuffer(rtx_ctx * c, float * rgb_f32, uint32_t * pac
     hipSetDevice(c->cfg.device);
     const size_t px = (size_t)c->cfg.width * c->cfg.height;
     HIP_OK(c, hipStreamSynchronize(c->stream));
-    if (rgb_f32)    HIP_OK(c, hipMemcpy(rgb_f32, c->d_fb_rgb.p, px * 12, hipMemcpyDeviceToHost));
-    if (packed_u32) HIP_OK(c, hipMemcpy(packed_u32, c->d_fb_packed.p, px * 4, hipMemcpyDeviceToHost));
+    if (rgb_f32)    HIP_OK(c, hipMemcpy(rgb_f32, c->ext_rgb ? c->ext_rgb : c->d_fb_rgb.p, px * 12, hipMemcpyDeviceToHost));
+    if (packed_u32) HIP_OK(c, hipMemcpy(packed_u32, c->ext_packed ? c->ext_packed : c->d_fb_packed.p, px * 4, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 
 extern "C" int rtx_framebuffer_device_ptrs(rtx_ctx * c, void ** rgb_f32_dev, void ** packed_u32_dev) {
     if (!c) return RTX_ERR_INVALID_ARG;
-    if (rgb_f32_dev) *rgb_f32_dev = c->d_fb_rgb.p;
-    if (packed_u32_dev) *packed_u32_dev = c->d_fb_packed.p;
+    if (rgb_f32_dev) *rgb_f32_dev = c->ext_rgb ? c->ext_rgb : c->d_fb_rgb.p;
+    if (packed_u32_dev) *packed_u32_dev = c->ext_packed ? c->ext_packed : c->d_fb_packed.p;
+    return RTX_OK;
+}
+
+extern "C" int rtx_bind_framebuffer(rtx_ctx * c, void * rgb_f32_dev, void * packed_u32_dev) {
+    if (!c || ((rgb_f32_dev == nullptr) != (packed_u32_dev == nullptr))) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    c->ext_rgb = rgb_f32_dev; c->ext_packed = packed_u32_dev;
+    return RTX_OK;
+}
+
+extern "C" int rtx_set_stream(rtx_ctx * c, void * hip_stream) {
+    if (!c) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return RTX_OK;
 }
 
 extern "C" int rtx_enable_kernel_timing(rtx_ctx * c, int32_t enable) {
     if (!c) return RTX_ERR_INVALID_ARG;
     c->timing = enable != 0;
+    c->times.clear(); c->event_next = 0;      // launches are recorded from now on, across render calls
     return RTX_OK;
 }
 

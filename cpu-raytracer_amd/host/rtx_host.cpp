@@ -334,7 +334,8 @@ struct BlasBuild {
 
 extern "C" int rtxh_blas_build(const float * positions, int32_t n, int32_t bins, rtx_bvh_node * nodes_out, int32_t * node_count_out, int32_t * order_out) {
     if (!positions || n <= 0 || !nodes_out || !node_count_out || !order_out) return RTX_ERR_INVALID_ARG;
-    if (bins < 4) bins = 4; if (bins > 256) bins = 256;
+    if (bins < 4) bins = 4;
+    if (bins > 256) bins = 256;
     BlasBuild b; b.pos = positions; b.bins = bins; b.tb.resize(n); b.cen.resize(n); b.order.resize(n);
     for (int i = 0; i < n; i++) {
         const float * p = positions + 9 * (size_t)i;
@@ -430,7 +431,7 @@ extern "C" int rtxh_atrium_generate(uint32_t seed, int32_t detail, rtxh_mesh * o
     if (!out || detail < 0 || detail > 8) return RTX_ERR_INVALID_ARG;
     MeshOut m; Rng rng = { seed };
     const float PI = 3.14159265358979f;
-    // tessellation multiplier: detail 4 ~ 265k triangles, detail 0 ~ 17k
+    // tessellation multiplier: detail 1 ~ 255k triangles (the cfg3 size), detail 0 ~ 64k, detail 4 ~ 1.6M
     const float q = 0.25f * (float)(detail + 1);
     auto T = [&](int base) { int v = (int)(base * q + 0.5f); return v < 2 ? 2 : v; };
     const float HX = 30.0f, HZ = 12.0f, HY = 18.0f;

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "..", "csrc", "librtx_hip.so")
 EXPORTS = ["rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_blas", "rtx_upload_materials",
            "rtx_upload_texture", "rtx_upload_sky", "rtx_set_frame", "rtx_render_tiles", "rtx_synchronize", "rtx_get_stats",
            "rtx_read_framebuffer", "rtx_framebuffer_device_ptrs", "rtx_last_kernel_times", "rtx_enable_kernel_timing",
-           "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample"]
+           "rtx_bind_framebuffer", "rtx_set_stream", "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample"]
 
 RTX_RENDER_COUNT_WORK = 1
 ERRORS = {1: "RTX_ERR_INVALID_ARG", 2: "RTX_ERR_NO_DEVICE", 3: "RTX_ERR_HIP", 4: "RTX_ERR_LIMIT", 5: "RTX_ERR_STATE", 6: "RTX_ERR_OOM"}
@@ -60,6 +60,8 @@ def load_library(path: Optional[str] = None):
     lib.rtx_framebuffer_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.rtx_last_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(f), i32, C.POINTER(i32)]
     lib.rtx_enable_kernel_timing.argtypes = [vp, i32]
+    lib.rtx_bind_framebuffer.argtypes = [vp, vp, vp]
+    lib.rtx_set_stream.argtypes = [vp, vp]
     lib.rtx_debug_libm.argtypes = [vp, i32, vp, vp, vp, i32]
     lib.rtx_debug_texture_sample.argtypes = [vp, i32, vp, vp, i32]
     lib.rtx_debug_sky_sample.argtypes = [vp, vp, vp, i32]
@@ -156,6 +158,12 @@ class Renderer:
         stats, work = self.stats()
         rgb, packed = self.framebuffer()
         return {"rgb": rgb, "packed": packed, "stats": stats, "work": work}
+
+    def bind_framebuffer(self, rgb_ptr: Optional[int], packed_ptr: Optional[int]):
+        self._chk(self.lib.rtx_bind_framebuffer(self.ctx, rgb_ptr, packed_ptr), "rtx_bind_framebuffer")
+
+    def set_stream(self, stream_handle: Optional[int]):
+        self._chk(self.lib.rtx_set_stream(self.ctx, stream_handle), "rtx_set_stream")
 
     def enable_timing(self, on: bool = True):
         self._chk(self.lib.rtx_enable_kernel_timing(self.ctx, 1 if on else 0), "rtx_enable_kernel_timing")

@@ -63,7 +63,6 @@ def _f32(a):
 def axis_angle(axis: Sequence[float], angle: float) -> np.ndarray:
     """Quaternion::axis_angle, Quaternion.h:24-34 (sinf/cosf in fp32)."""
     half = np.float32(0.5) * np.float32(angle)
-    s = np.float32(math.sin(float(half)))   # libm sinf == correctly rounded double sin for all but rare cases; data only
     s = np.sin(half, dtype=np.float32)
     c = np.cos(half, dtype=np.float32)
     a = _f32(axis)
@@ -217,9 +216,9 @@ def make_config(width, height, bounces, mip_filter=1, texture_mode=2, stack_size
     return cfg
 
 
-def atrium_scene(width: int = 1920, height: int = 1080, bounces: int = 3, detail: int = 4, seed: int = 0x5EED0003,
+def atrium_scene(width: int = 1920, height: int = 1080, bounces: int = 3, detail: int = 1, seed: int = 0x5EED0003,
                  mip_filter: int = 1, bins: int = 32) -> sio.Scene:
-    """BASELINE.json configs[2]: Sponza-class (~265k triangles at detail 4) stand-in, 3 lights,
+    """BASELINE.json configs[2]: Sponza-class (255 296 triangles at detail 1) stand-in, 3 lights,
     reflect/refract depth 3, anisotropic mip filter (the shipped default, Config.h:53)."""
     mesh = RtxhMesh()
     assert lib().rtxh_atrium_generate(seed, detail, C.byref(mesh)) == 0

@@ -274,9 +274,20 @@ int rtx_read_framebuffer(rtx_ctx * ctx, float * rgb_f32, uint32_t * packed_u32);
 /* Device addresses of the same two buffers (for RCCL / zero-copy consumers). */
 int rtx_framebuffer_device_ptrs(rtx_ctx * ctx, void ** rgb_f32_dev, void ** packed_u32_dev);
 
-/* Timing of the kernels launched by the last rtx_render_tiles call, measured
- * with HIP events on the context's stream.  names/ms hold up to `capacity`
- * entries; *count receives the number of kernel launches recorded.            */
+/* Render into caller-owned device buffers (e.g. tensors of a framework that also owns the RCCL
+ * communicator) instead of the context's own framebuffer; NULL restores the internal one.  The
+ * buffers must hold width*height*3 floats and width*height uint32.                                */
+int rtx_bind_framebuffer(rtx_ctx * ctx, void * rgb_f32_dev, void * packed_u32_dev);
+
+/* Enqueue all work of this context on a caller-owned HIP stream (hipStream_t passed as void *);
+ * NULL restores the context's own stream.  Lets a caller order rendering against its own
+ * kernels / collectives without host synchronisation.                                              */
+int rtx_set_stream(rtx_ctx * ctx, void * hip_stream);
+
+/* Timing of every kernel launched since rtx_enable_kernel_timing(ctx, 1),
+ * measured with HIP events on the stream the kernels are launched on.
+ * names/ms hold up to `capacity` entries; *count receives the number of
+ * kernel launches recorded.                                                    */
 int rtx_last_kernel_times(rtx_ctx * ctx, const char ** names, float * ms, int32_t capacity, int32_t * count);
 int rtx_enable_kernel_timing(rtx_ctx * ctx, int32_t enable);
 
