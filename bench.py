@@ -35,6 +35,13 @@ def algorithmic_bytes_closest(work, level0_rays):
             + 36 * work["tri_tests_closest"] + 24 * max(rays - level0_rays, 0) + 20 * rays)
 
 
+def algorithmic_bytes_any(work):
+    """k_trace<any>: node / instance / triangle bytes as above, 28 B shadow ray read (origin, direction,
+    max distance) and 4 B occlusion flag written per shadow ray."""
+    return (32 * (work["tlas_nodes_any"] + work["blas_nodes_any"]) + 64 * work["instances_any"]
+            + 36 * work["tri_tests_any"] + 32 * work["any_rays"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,7 +61,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from pyrtx import api, host
+    from pyrtx import api, host, shard
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the render path)")
@@ -84,40 +91,15 @@ def main():
     r.set_stream(stream.cuda_stream)
 
     T = sc.tile_count
-    first, stride = rank, world                                  # tile t belongs to GPU t mod N
-    count = (T - rank + world - 1) // world if rank < T else 0
+    first, stride, count = shard.shard_args(T, rank, world)     # tile t belongs to GPU t mod N
 
     # ---- gather plumbing (N > 1): each rank sends only the pixels of its own tiles ---------------------
-    if world > 1:
-        tcx = sc.tile_count_x
-        per_rank = (T + world - 1) // world
-
-        def tile_pixels(rk):
-            idx = np.full((per_rank, 32, 32), -1, np.int64)
-            for k, t in enumerate(range(rk, T, world)):
-                ty, tx = (t // tcx) * 32, (t % tcx) * 32
-                ys, xs = np.mgrid[ty:ty + 32, tx:tx + 32]
-                ok = (ys < H) & (xs < W)
-                idx[k] = np.where(ok, ys * W + xs, -1)
-            return idx.reshape(-1)
-        my_idx_np = tile_pixels(rank)
-        my_idx = torch.from_numpy(np.where(my_idx_np >= 0, my_idx_np, 0)).cuda()
-        send = torch.zeros(per_rank * 1024, dtype=torch.int32, device="cuda")
-        if rank == 0:
-            recv = [torch.zeros_like(send) for _ in range(world)]
-            all_idx = [tile_pixels(rk) for rk in range(world)]
-            valid = [torch.from_numpy(np.nonzero(a >= 0)[0]).cuda() for a in all_idx]
-            dest = [torch.from_numpy(a[a >= 0]).cuda() for a in all_idx]
-            final = torch.zeros(H * W, dtype=torch.int32, device="cuda")
+    gather = shard.TileGather(W, H, rank, world, "cuda") if world > 1 else None
 
     def step():
         r.render_async(first, stride, count)
-        if world > 1:
-            torch.index_select(fb_packed, 0, my_idx, out=send)
-            dist.gather(send, recv if rank == 0 else None, dst=0)
-            if rank == 0:                                           # un-swizzle tile-major -> raster on the root
-                for rk in range(world):
-                    final.index_copy_(0, dest[rk], recv[rk].index_select(0, valid[rk]))
+        if gather is not None:
+            gather(fb_packed)
 
     def sync():
         torch.cuda.synchronize()
@@ -157,11 +139,20 @@ def main():
         for name, ms in ktimes:
             by_kernel.setdefault(name, []).append(ms)
         kern = {k: {"launches": len(v), "avg_ms": float(np.mean(v)), "total_ms_per_step": float(np.sum(v)) / max(args.steps, 1)} for k, v in by_kernel.items()}
-        dom = "k_trace_closest"
-        bytes_frame = algorithmic_bytes_closest(work, level0_rays)
-        launches_per_frame = len(by_kernel.get(dom, [])) / max(args.steps, 1)
+        levels = int(sc.config["bounces"][0]) + 1
+        alg = {"k_trace_closest": (algorithmic_bytes_closest(work, level0_rays), work["closest_rays"]),
+               "k_trace_any": (algorithmic_bytes_any(work), work["any_rays"])}
+        for k, (b, n) in alg.items():
+            if k in kern:
+                # one launch per level and frame: bytes per launch = bytes per frame / levels
+                kern[k]["algorithmic_GBps"] = round((b / levels) / (kern[k]["avg_ms"] * 1e-3) / 1e9, 2)
+                kern[k]["Grays_per_s"] = round((n / levels) / (kern[k]["avg_ms"] * 1e-3) / 1e9, 4)
+                kern[k]["bytes_per_ray"] = round(b / max(n, 1), 1)
+        dom = max((k for k in alg if k in kern), key=lambda k: kern[k]["total_ms_per_step"], default="k_trace_closest")
+        bytes_frame = alg[dom][0]
+        launches_per_frame = levels
         avg_s = kern[dom]["avg_ms"] * 1e-3 if dom in kern else float("nan")
-        achieved = (bytes_frame / max(launches_per_frame, 1)) / avg_s / 1e9 if dom in kern else None
+        achieved = (bytes_frame / launches_per_frame) / avg_s / 1e9 if dom in kern else None
         traffic = None
         tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
@@ -183,7 +174,7 @@ def main():
                          "frac": None if achieved is None else round(achieved / 8000.0, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_frame / max(launches_per_frame, 1)),
                          "avg_launch_ms": None if dom not in kern else round(kern[dom]["avg_ms"], 5),
-                         "bytes_per_ray": round(bytes_frame / max(work["closest_rays"], 1), 1)},
+                         "bytes_per_ray": round(bytes_frame / max(alg[dom][1], 1), 1)},
         }
         # ---- CPU baseline: the oracle (port of the reference's lane-1 path) on this box's host cores ------
         if world == 1 and args.cpu_seconds > 0:

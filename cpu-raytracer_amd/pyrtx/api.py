@@ -169,7 +169,7 @@ class Renderer:
         self._chk(self.lib.rtx_enable_kernel_timing(self.ctx, 1 if on else 0), "rtx_enable_kernel_timing")
 
     def kernel_times(self):
-        cap = 256
+        cap = 65536
         names = (C.c_char_p * cap)(); ms = (C.c_float * cap)(); n = C.c_int32()
         self._chk(self.lib.rtx_last_kernel_times(self.ctx, names, ms, cap, C.byref(n)), "rtx_last_kernel_times")
         return [(names[i].decode(), float(ms[i])) for i in range(min(n.value, cap))]
