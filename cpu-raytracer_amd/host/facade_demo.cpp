@@ -1,0 +1,38 @@
+// facade_demo — drives the render path through the reference-shaped C++ facade (rtx_facade.hpp):
+//   Scene scene; scene.update(dt); raytracer.render_frame(window, stats);
+// usage: facade_demo <scene.rtxs> <width> <height> <bounces> <mip_filter> <texture_mode> [out.ppm]
+// Prints the PerformanceStats and an FNV-1a hash of the packed framebuffer (compared with the Python path in tests).
+#include <cstdio>
+#include <cstdlib>
+#include "rtx_facade.hpp"
+
+int main(int argc, char ** argv) {
+    if (argc < 7) { std::fprintf(stderr, "usage: facade_demo scene.rtxs W H bounces mip_filter texture_mode [out.ppm]\n"); return 2; }
+    try {
+        rtx::Config cfg;
+        cfg.SCREEN_WIDTH = std::atoi(argv[2]); cfg.SCREEN_HEIGHT = std::atoi(argv[3]); cfg.NUMBER_OF_BOUNCES = std::atoi(argv[4]);
+        cfg.MIPMAP_FILTER = std::atoi(argv[5]); cfg.TEXTURE_SAMPLE_MODE = std::atoi(argv[6]);
+        rtx::Scene scene(cfg, 1.9198622f /* 110 degrees, Scene.cpp:7 */);
+        rtx::load_rtxs(argv[1], scene);
+        scene.camera.resize(cfg.SCREEN_WIDTH, cfg.SCREEN_HEIGHT);
+        scene.upload();
+        scene.update(0.0f);                       // instance matrices + TLAS are REBUILT here from position/rotation
+
+        rtx::Window window(cfg.SCREEN_WIDTH, cfg.SCREEN_HEIGHT);
+        rtx::Raytracer raytracer; raytracer.scene = &scene;
+        rtx::PerformanceStats stats;
+        raytracer.render_frame(window, stats);
+
+        uint64_t h = 1469598103934665603ull;
+        for (uint32_t p : window.frame_buffer) for (int k = 0; k < 4; k++) { h ^= (p >> (8 * k)) & 0xff; h *= 1099511628211ull; }
+        std::printf("{\"primary\": %lld, \"shadow\": %lld, \"reflection\": %lld, \"refraction\": %lld, \"fnv1a\": \"%016llx\"}\n",
+                    stats.num_primary_rays, stats.num_shadow_rays, stats.num_reflection_rays, stats.num_refraction_rays, (unsigned long long)h);
+        if (argc > 7) {
+            FILE * f = std::fopen(argv[7], "wb");
+            std::fprintf(f, "P6\n%d %d\n255\n", window.width, window.height);
+            for (uint32_t p : window.frame_buffer) { unsigned char c[3] = { (unsigned char)(p >> 16), (unsigned char)(p >> 8), (unsigned char)p }; std::fwrite(c, 1, 3, f); }
+            std::fclose(f);
+        }
+    } catch (const std::exception & e) { std::fprintf(stderr, "facade_demo: %s\n", e.what()); return 1; }
+    return 0;
+}
