@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget (0 disables)")
+    ap.add_argument("--simple-trace", action="store_true", help="A/B: plain pop-and-test traversal kernels")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,7 +98,7 @@ def main():
     gather = shard.TileGather(W, H, rank, world, "cuda") if world > 1 else None
 
     def step():
-        r.render_async(first, stride, count)
+        r.render_async(first, stride, count, simple_trace=args.simple_trace)
         if gather is not None:
             gather(fb_packed)
 

@@ -56,7 +56,7 @@ struct rtx_ctx {
     DevBuf qb[20];
     size_t slots_alloc = 0, shadow_alloc = 0;
     DevBuf d_counters, d_spill, d_fb_rgb, d_fb_packed;
-    int trace_blocks_closest = 0, trace_blocks_any = 0;
+    int trace_blocks_closest = 0, trace_blocks_any = 0, trace_blocks_count = 0;
 
     rtx_stats stats_acc; rtx_work_counters work_acc; uint32_t err_flags_acc = 0;
     bool stats_pending = false;
@@ -152,11 +152,14 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     hipMemset(c->d_fb_packed.p, 0, px * 4);
 
     int bpc = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace<false, false>, RTX_TRACE_BLOCK, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<false>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_closest = c->n_cu * (bpc > 0 ? bpc : 2);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace<true, false>, RTX_TRACE_BLOCK, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<true>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_any = c->n_cu * (bpc > 0 ? bpc : 2);
-    const int max_blocks = c->trace_blocks_closest > c->trace_blocks_any ? c->trace_blocks_closest : c->trace_blocks_any;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace<false, true>, RTX_TRACE_BLOCK, 0);
+    c->trace_blocks_count = c->n_cu * (bpc > 0 ? bpc : 2);
+    int max_blocks = c->trace_blocks_closest > c->trace_blocks_any ? c->trace_blocks_closest : c->trace_blocks_any;
+    if (c->trace_blocks_count > max_blocks) max_blocks = c->trace_blocks_count;
     c->q.spill_threads = max_blocks * RTX_TRACE_BLOCK;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4);
     if (rc) { rtx_destroy(c); return rc; }
@@ -386,6 +389,7 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
     if (tile_count > 0 && first_tile + (int64_t)(tile_count - 1) * tile_stride >= (int64_t)tcx * tcy) return RTX_ERR_INVALID_ARG;
     hipSetDevice(c->cfg.device);
     const bool count_work = (flags & RTX_RENDER_COUNT_WORK) != 0;
+    const bool simple = (flags & RTX_RENDER_SIMPLE_TRACE) != 0;
 
     // stats of this call: reset accumulators (WorkerThread.cpp:120 zeroes them per frame)
     HIP_OK(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), c->stream));
@@ -406,16 +410,18 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, q.counters, (uint32_t)q.primary_slots);
         for (int level = 0; level < levels; level++) {
             launch_timed(c, "k_trace_closest", [&] {
-                if (count_work) hipLaunchKernelGGL((k_trace<false, true>),  dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else            hipLaunchKernelGGL((k_trace<false, false>), dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                if (count_work)   hipLaunchKernelGGL((k_trace<false, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else if (simple)  hipLaunchKernelGGL((k_trace<false, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else              hipLaunchKernelGGL((k_trace_fast<false>),   dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
             });
             launch_timed(c, "k_shade", [&] {
                 if (count_work) hipLaunchKernelGGL((k_shade<true>),  dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
                 else            hipLaunchKernelGGL((k_shade<false>), dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
             });
             if (sc.light_count > 0) launch_timed(c, "k_trace_any", [&] {
-                if (count_work) hipLaunchKernelGGL((k_trace<true, true>),  dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else            hipLaunchKernelGGL((k_trace<true, false>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                if (count_work)   hipLaunchKernelGGL((k_trace<true, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else if (simple)  hipLaunchKernelGGL((k_trace<true, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else              hipLaunchKernelGGL((k_trace_fast<true>),   dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
             });
         }
         for (int level = levels - 1; level >= 0; level--)

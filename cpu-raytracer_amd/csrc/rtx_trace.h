@@ -298,3 +298,210 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
         }
     }
 }
+
+
+// =================================================================================================
+// k_trace_fast — same rays, same per-lane traversal ORDER and therefore the same hits as k_trace,
+// with two changes that cut the number of dependent memory round trips per ray roughly in half:
+//
+//  * child PAIR fetch: the two children of an inner node are adjacent (BVHNode.h:10-16,
+//    BVHBuilders.h:20-21), so one 64-byte fetch (4 x dwordx4) brings both boxes; both are slab-tested
+//    at once.
+//  * early filter: a child that fails the slab test now is not pushed.  This is exact: the reference
+//    tests a node when it POPS it, against a closest distance that can only have shrunk since, and
+//    `t_near < min(min(D, tx), min(ty, tz))` is monotone in D — failing now implies failing later.
+//    The near child is processed immediately (the reference pops it next, with D unchanged); the far
+//    child is pushed and RE-TESTED when popped, against the then-current D, which is exactly the
+//    reference's pop-time test.  For shadow rays D never changes, so the re-test is skipped.
+//
+// Work counters are produced by k_trace<ANY, true> (reference-order accounting); this kernel has none.
+template <bool ANY>
+__global__ __launch_bounds__(RTX_TRACE_BLOCK)
+void k_trace_fast(const DevScene sc, const DevQueues q, const int level) {
+    __shared__ int lds_stack[RTX_TRACE_BLOCK / RTX_WAVE][RTX_LDS_STACK][RTX_WAVE];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int * const stk = &lds_stack[wave][0][lane];
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    int * const spill = q.spill + gtid;
+    const int spill_stride = q.spill_threads;
+
+    DevCounters * const ctr = q.counters;
+    const uint32_t lit_n = ctr->lit_count[level];
+    const uint32_t total = ANY ? lit_n * (uint32_t)sc.light_count : ctr->ray_count[level];
+    uint32_t * const head = ANY ? &ctr->fetch_any[level] : &ctr->fetch_closest[level];
+    const int lit_cap = q.level_cap[level];
+    const bool ordered = sc.traversal_strategy == RTX_TRAVERSE_ORDERED;
+
+    bool has_ray = false, have_cur = false;
+    uint32_t out_slot = 0;
+    v3 wo = V3(0, 0, 0), wd = wo, winv = wo, co = wo, cd = wo, cinv = wo;
+    float tcur = 0.0f;
+    int best_prim = PRIM_NONE, best_tri = 0; float best_u = 0.0f, best_v = 0.0f;
+    int sp = 0, floor_sp = -1, cur_inst = 0;
+    int cur_first = 0, cur_cnt = 0;                 // the node being visited: it has already passed its slab test
+    const float4 * cur_nodes = sc.tlas_nodes;
+    const float4 * cur_tris  = nullptr;
+    uint32_t n_stackerr = 0;
+
+    auto push = [&](int e) {
+        if (sp < RTX_LDS_STACK) stk[sp * RTX_WAVE] = e;
+        else if (sp < RTX_MAX_STACK) spill[(sp - RTX_LDS_STACK) * spill_stride] = e;
+        else { n_stackerr = 1; return; }
+        sp++;
+    };
+    auto pop = [&]() -> int {
+        sp--;
+        return (sp < RTX_LDS_STACK) ? stk[sp * RTX_WAVE] : spill[(sp - RTX_LDS_STACK) * spill_stride];
+    };
+    auto finish = [&]() {
+        if (ANY) q.socc[out_slot] = 0u;
+        else { q.h0[out_slot] = make_float4(tcur, best_u, best_v, as_f(best_prim)); q.h1[out_slot] = best_tri; }
+        has_ray = false; have_cur = false;
+    };
+
+    bool exhausted = false;
+    for (;;) {
+        const unsigned long long idle = __ballot(!has_ray);
+        const int n_idle = __popcll(idle);
+        if (!exhausted && n_idle >= RTX_REFILL_MIN) {
+            const int leader = __ffsll((long long)idle) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(head, (uint32_t)n_idle);
+            base = __shfl(base, leader);
+            if (base + (uint32_t)n_idle >= total) exhausted = true;
+            const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!has_ray && idx < total) {
+                bool live = true;
+                if (ANY) {
+                    const uint32_t light = idx / lit_n, rank = idx - light * lit_n;
+                    out_slot = (uint32_t)q.shadow_base[level] + light * (uint32_t)lit_cap + rank;
+                    const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot];
+                    wo = V3(s0.x, s0.y, s0.z); tcur = s0.w; wd = V3(s1.x, s1.y, s1.z);
+                } else {
+                    out_slot = (uint32_t)q.level_base[level] + idx;
+                    if (level == 0) {
+                        int px, py;
+                        live = primary_pixel(sc, q, idx, px, py);
+                        RayFull r;
+                        if (live) { primary_ray(sc, px, py, r, false); wo = r.o; wd = r.d; }
+                    } else {
+                        const float4 r0 = q.r0[out_slot], r1 = q.r1[out_slot];
+                        wo = V3(r0.x, r0.y, r0.z); wd = V3(r0.w, r1.x, r1.y);
+                    }
+                    tcur = INFINITY;
+                    best_prim = PRIM_NONE; best_tri = 0; best_u = 0.0f; best_v = 0.0f;
+                }
+                if (live) {
+                    bool done = false;
+                    for (int i = 0; i < sc.sphere_count; i++) {
+                        if (ANY) { if (sphere_any(sc.spheres[i], wo, wd, tcur)) { done = true; break; } }
+                        else { float t; if (sphere_closest(sc.spheres[i], wo, wd, tcur, t)) { tcur = t; best_prim = PRIM_SPHERE | i; } }
+                    }
+                    if (!done) for (int i = 0; i < sc.plane_count; i++) {
+                        const float t = plane_t(sc.planes[i], wo, wd);
+                        if (ANY) { if ((t > RAY_EPSILON) & (t < tcur)) { done = true; break; } }
+                        else if ((t > RAY_EPSILON) & (t < tcur)) { tcur = t; best_prim = PRIM_PLANE | i; }
+                    }
+                    if (ANY && done) {
+                        q.socc[out_slot] = 1u;
+                    } else if (sc.tlas_node_count > 0) {
+                        winv = vrcp(wd);
+                        co = wo; cd = wd; cinv = winv;
+                        cur_nodes = sc.tlas_nodes; floor_sp = -1; sp = 0;
+                        has_ray = true;
+                        // TLAS root: pushed, popped and tested by the reference (TopLevelBVH.cpp:58-67)
+                        const float4 na = cur_nodes[0], nb = cur_nodes[1];
+                        if (slab_test(na, nb, co, cinv, tcur)) { cur_first = as_i(na.w); cur_cnt = as_i(nb.w); have_cur = true; }
+                        else finish();
+                    } else {
+                        if (ANY) q.socc[out_slot] = 0u;
+                        else { q.h0[out_slot] = make_float4(tcur, 0.0f, 0.0f, as_f(best_prim)); q.h1[out_slot] = 0; }
+                    }
+                } else if (!ANY) {
+                    q.h0[out_slot] = make_float4(INFINITY, 0.0f, 0.0f, as_f(PRIM_NONE));
+                    q.h1[out_slot] = -1;
+                }
+            }
+        }
+        if (__ballot(has_ray) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+
+        for (int it = 0; it < RTX_TRACE_STEPS; it++) {
+            // ---- A: inner node: fetch the child pair, test both, descend into the near one ----
+            if (has_ray && have_cur && (cur_cnt & 0x3fffffff) == 0) {
+                const int left = cur_first;
+                const float4 la = cur_nodes[2 * left], lb = cur_nodes[2 * left + 1], ra = cur_nodes[2 * left + 2], rb = cur_nodes[2 * left + 3];
+                const bool pl = slab_test(la, lb, co, cinv, tcur);
+                const bool pr = slab_test(ra, rb, co, cinv, tcur);
+                bool left_first = true;                                  // BVHNode::should_visit_left_first, BVHNode.h:30-40
+                if (ordered) {
+                    const int axis = (int)((uint32_t)cur_cnt >> 30);
+                    if (axis == 1) left_first = cd.x > 0.0f;
+                    else if (axis == 2) left_first = cd.y > 0.0f;
+                    else if (axis == 3) left_first = cd.z > 0.0f;
+                }
+                const bool p_near = left_first ? pl : pr, p_far = left_first ? pr : pl;
+                const int near_first = left_first ? as_i(la.w) : as_i(ra.w), near_cnt = left_first ? as_i(lb.w) : as_i(rb.w);
+                const int far_first  = left_first ? as_i(ra.w) : as_i(la.w), far_cnt  = left_first ? as_i(rb.w) : as_i(lb.w);
+                if (p_near) {
+                    if (p_far) push(left_first ? left + 1 : left);
+                    cur_first = near_first; cur_cnt = near_cnt;
+                } else if (p_far) {
+                    cur_first = far_first; cur_cnt = far_cnt;
+                } else have_cur = false;
+            }
+            // ---- B: leaf ----
+            if (has_ray && have_cur && (cur_cnt & 0x3fffffff) > 0) {
+                have_cur = false;
+                const int first = cur_first, cnt = cur_cnt;
+                if (floor_sp >= 0) {
+                    for (int i = first; i < first + cnt; i++) {
+                        const float4 p0 = cur_tris[3 * i], e1 = cur_tris[3 * i + 1], e2 = cur_tris[3 * i + 2];
+                        const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
+                        const v3 h = vcross(cd, edge_2);
+                        const float a = vdot(edge_1, h);
+                        const float f = 1.0f / a;
+                        const v3 s = vsub(co, V3(p0.x, p0.y, p0.z));
+                        const float u = f * vdot(s, h);
+                        if (!((u > 0.0f) & (u < 1.0f))) continue;
+                        const v3 qq = vcross(s, edge_1);
+                        const float v = f * vdot(cd, qq);
+                        if (!((v > 0.0f) & ((u + v) < 1.0f))) continue;
+                        const float t = f * vdot(edge_2, qq);
+                        if (!((t > RAY_EPSILON) & (t < tcur))) continue;
+                        if (ANY) { q.socc[out_slot] = 1u; has_ray = false; break; }
+                        tcur = t; best_u = u; best_v = v; best_tri = i; best_prim = PRIM_TRI | cur_inst;
+                    }
+                } else {
+                    for (int i = first + cnt - 1; i >= first; i--) push(~i);
+                }
+            }
+            // ---- C: pop ----
+            if (has_ray && !have_cur) {
+                if (floor_sp >= 0 && sp == floor_sp) { floor_sp = -1; co = wo; cd = wd; cinv = winv; cur_nodes = sc.tlas_nodes; }
+                if (sp == 0) { finish(); continue; }
+                const int e = pop();
+                if (e < 0) {
+                    const int inst = sc.tlas_indices[~e];                // Mesh::trace / intersect, Mesh.cpp:17-40
+                    const rtx_instance & I = sc.instances[inst];
+                    co = xform_pos(I.world_inv, wo);
+                    cd = xform_dir(I.world_inv, wd);
+                    cinv = vrcp(cd);
+                    const DevBlas & B = sc.blas[I.blas_id];
+                    cur_nodes = B.nodes; cur_tris = B.tri_hot; cur_inst = inst;
+                    floor_sp = sp;
+                    const float4 na = cur_nodes[0], nb = cur_nodes[1];    // BLAS root
+                    if (slab_test(na, nb, co, cinv, tcur)) { cur_first = as_i(na.w); cur_cnt = as_i(nb.w); have_cur = true; }
+                } else {
+                    // far child: the reference tests it now, against the current closest distance
+                    const float4 na = cur_nodes[2 * e], nb = cur_nodes[2 * e + 1];
+                    if (ANY || slab_test(na, nb, co, cinv, tcur)) { cur_first = as_i(na.w); cur_cnt = as_i(nb.w); have_cur = true; }
+                }
+            }
+        }
+    }
+    if (n_stackerr) atomicOr(&ctr->error_flags, ERR_STACK_OVERFLOW);
+}

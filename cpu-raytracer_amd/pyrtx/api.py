@@ -23,6 +23,7 @@ EXPORTS = ["rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rt
            "rtx_bind_framebuffer", "rtx_set_stream", "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample"]
 
 RTX_RENDER_COUNT_WORK = 1
+RTX_RENDER_SIMPLE_TRACE = 2
 ERRORS = {1: "RTX_ERR_INVALID_ARG", 2: "RTX_ERR_NO_DEVICE", 3: "RTX_ERR_HIP", 4: "RTX_ERR_LIMIT", 5: "RTX_ERR_STATE", 6: "RTX_ERR_OOM"}
 
 _lib = None
@@ -128,10 +129,12 @@ class Renderer:
         fill_frame(fr, sc, keep)
         self._chk(self.lib.rtx_set_frame(self.ctx, C.byref(fr)), "rtx_set_frame")
 
-    def render_async(self, first_tile: int = 0, tile_stride: int = 1, tile_count: Optional[int] = None, count_work: bool = False):
+    def render_async(self, first_tile: int = 0, tile_stride: int = 1, tile_count: Optional[int] = None, count_work: bool = False,
+                     simple_trace: bool = False):
         if tile_count is None:
             tile_count = (self.scene.tile_count - first_tile + tile_stride - 1) // tile_stride
-        self._chk(self.lib.rtx_render_tiles(self.ctx, first_tile, tile_stride, tile_count, RTX_RENDER_COUNT_WORK if count_work else 0), "rtx_render_tiles")
+        flags = (RTX_RENDER_COUNT_WORK if count_work else 0) | (RTX_RENDER_SIMPLE_TRACE if simple_trace else 0)
+        self._chk(self.lib.rtx_render_tiles(self.ctx, first_tile, tile_stride, tile_count, flags), "rtx_render_tiles")
 
     def synchronize(self):
         self._chk(self.lib.rtx_synchronize(self.ctx), "rtx_synchronize")
@@ -153,8 +156,9 @@ class Renderer:
         self._chk(self.lib.rtx_framebuffer_device_ptrs(self.ctx, C.byref(a), C.byref(b)), "rtx_framebuffer_device_ptrs")
         return a.value, b.value
 
-    def render(self, first_tile: int = 0, tile_stride: int = 1, tile_count: Optional[int] = None, count_work: bool = False) -> Dict:
-        self.render_async(first_tile, tile_stride, tile_count, count_work)
+    def render(self, first_tile: int = 0, tile_stride: int = 1, tile_count: Optional[int] = None, count_work: bool = False,
+               simple_trace: bool = False) -> Dict:
+        self.render_async(first_tile, tile_stride, tile_count, count_work, simple_trace)
         stats, work = self.stats()
         rgb, packed = self.framebuffer()
         return {"rgb": rgb, "packed": packed, "stats": stats, "work": work}

@@ -250,7 +250,8 @@ int rtx_upload_sky(rtx_ctx * ctx, const float * texels_rgb, int32_t size);
 int rtx_set_frame(rtx_ctx * ctx, const rtx_frame * frame);
 
 enum {
-    RTX_RENDER_COUNT_WORK = 1          /* also fill rtx_work_counters (instrumented kernels) */
+    RTX_RENDER_COUNT_WORK = 1,         /* also fill rtx_work_counters (instrumented kernels) */
+    RTX_RENDER_SIMPLE_TRACE = 2        /* use the plain pop-and-test traversal kernels (A/B reference for the pair-fetch kernels) */
 };
 
 /* Renders tiles first_tile + i*tile_stride, i in [0, tile_count), numbered as

@@ -111,3 +111,27 @@ def test_ragged_resolution(api):
     ref = orc.OracleScene(sc).render(threads=8)
     assert np.array_equal(out["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
     assert out["stats"] == ref["stats"]
+
+
+@pytest.mark.parametrize("name", ["materials_aniso", "dynamic", "tori16"])
+def test_pair_fetch_kernels_equal_plain_traversal(api, name):
+    """k_trace_fast (child-pair fetch + early filter) must reproduce the plain pop-and-test kernels bit for bit."""
+    sc, _ = util.load_golden(name)
+    r = api.Renderer(sc)
+    a = r.render()
+    b = r.render(simple_trace=True)
+    assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    assert a["stats"] == b["stats"]
+
+
+def test_atrium_cfg3_small_matches_oracle(api):
+    """The cfg3 workload (own BVH builder, 64k-triangle detail level) at reduced resolution vs the oracle."""
+    import orc
+    from pyrtx import host
+    sc = host.atrium_scene(480, 270, 3, detail=0)
+    out = api.Renderer(sc).render()
+    ref = orc.OracleScene(sc).render(threads=8)
+    assert out["stats"] == ref["stats"]
+    d = np.abs(out["rgb"].astype(np.float64) - ref["rgb"].astype(np.float64))
+    assert np.nanmax(d) < TOL
+    assert np.array_equal(out["packed"], ref["packed"])
