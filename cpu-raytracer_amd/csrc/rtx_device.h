@@ -10,7 +10,9 @@
 #include "../../include/rtx.h"
 
 #define RTX_MAX_LEVELS   12          // NUMBER_OF_BOUNCES + 1 wavefront levels supported
-#define RTX_LDS_STACK    32          // traversal stack entries kept in LDS per lane; deeper entries spill to HBM
+#ifndef RTX_LDS_STACK
+#define RTX_LDS_STACK    16          // traversal stack entries kept in LDS per lane (4 KiB per wave); deeper entries spill to HBM
+#endif
 #define RTX_WAVE         64
 #define RTX_TRACE_BLOCK  256         // 4 waves per workgroup
 

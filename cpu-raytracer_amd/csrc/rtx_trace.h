@@ -17,8 +17,18 @@
 #include "rtx_math.h"
 #include "rtx_device.h"
 
-#define RTX_REFILL_MIN   16     // refill a wave when this many lanes are idle
-#define RTX_TRACE_STEPS  8      // traversal steps between refill checks
+#ifndef RTX_REFILL_MIN
+#define RTX_REFILL_MIN   48     // refill a wave when this many lanes are idle (A/B on MI355X: 16 -> 5.57 ms, 48 -> 4.39 ms per cfg3 frame)
+#endif
+#ifndef RTX_TRACE_STEPS
+#define RTX_TRACE_STEPS  32     // traversal steps between refill checks
+#endif
+#ifndef RTX_WAVES_ANY
+#define RTX_WAVES_ANY     1     // __launch_bounds__ min waves per SIMD for the shadow-ray kernel
+#endif
+#ifndef RTX_WAVES_CLOSEST
+#define RTX_WAVES_CLOSEST 1
+#endif
 #define RAY_EPSILON      0.005f // Ray.h:5
 
 // Slot -> pixel of a primary ray.  1024 slots per tile, a wave covers an 8x8 pixel block.
@@ -316,7 +326,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
 //
 // Work counters are produced by k_trace<ANY, true> (reference-order accounting); this kernel has none.
 template <bool ANY>
-__global__ __launch_bounds__(RTX_TRACE_BLOCK)
+__global__ __launch_bounds__(RTX_TRACE_BLOCK, ANY ? RTX_WAVES_ANY : RTX_WAVES_CLOSEST)
 void k_trace_fast(const DevScene sc, const DevQueues q, const int level) {
     __shared__ int lds_stack[RTX_TRACE_BLOCK / RTX_WAVE][RTX_LDS_STACK][RTX_WAVE];
     const int lane = threadIdx.x & 63;
@@ -447,7 +457,14 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level) {
                 const int near_first = left_first ? as_i(la.w) : as_i(ra.w), near_cnt = left_first ? as_i(lb.w) : as_i(rb.w);
                 const int far_first  = left_first ? as_i(ra.w) : as_i(la.w), far_cnt  = left_first ? as_i(rb.w) : as_i(lb.w);
                 if (p_near) {
-                    if (p_far) push(left_first ? left + 1 : left);
+                    if (p_far) {
+                        // shadow rays never re-test a far child (their max distance is constant), so its (first, count)
+                        // travel on the stack and the pop needs no memory access; closest-hit rays push the node index
+                        const int far_leaf = far_cnt & 0x3fffffff;
+                        if (ANY && (uint32_t)far_first < (1u << 24) && far_leaf < 16)
+                            push((int)(0x40000000u | (((uint32_t)far_cnt >> 30) << 28) | ((uint32_t)far_leaf << 24) | (uint32_t)far_first));
+                        else push(left_first ? left + 1 : left);
+                    }
                     cur_first = near_first; cur_cnt = near_cnt;
                 } else if (p_far) {
                     cur_first = far_first; cur_cnt = far_cnt;
@@ -495,6 +512,10 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level) {
                     floor_sp = sp;
                     const float4 na = cur_nodes[0], nb = cur_nodes[1];    // BLAS root
                     if (slab_test(na, nb, co, cinv, tcur)) { cur_first = as_i(na.w); cur_cnt = as_i(nb.w); have_cur = true; }
+                } else if (ANY && (e & 0x40000000)) {
+                    cur_first = e & 0x00ffffff;
+                    cur_cnt = (int)((((uint32_t)e >> 28) & 3u) << 30) | ((e >> 24) & 15);
+                    have_cur = true;
                 } else {
                     // far child: the reference tests it now, against the current closest distance
                     const float4 na = cur_nodes[2 * e], nb = cur_nodes[2 * e + 1];

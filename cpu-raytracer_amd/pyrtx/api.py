@@ -40,7 +40,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.abspath(path or LIB_PATH)
+    path = os.path.abspath(path or os.environ.get("RTX_HIP_LIB") or LIB_PATH)
     if not os.path.exists(path):
         raise FileNotFoundError(f"{path} is missing: the HIP extension has not been built (python -c 'import __graft_entry__ as g; g.build()')")
     lib = C.CDLL(path)
