@@ -323,7 +323,9 @@ static int plan_batch(rtx_ctx * c, int tiles, int & out_tiles) {
     // worst case: every hit spawns two children -> level d holds P * 2^d rays
     const int levels = c->cfg.bounces + 1;
     const long long per_tile = 1024ll * ((1ll << levels) - 1);
-    long long t = SLOT_BUDGET / per_tile;
+    long long budget = SLOT_BUDGET;
+    if (const char * e = getenv("RTX_SLOT_BUDGET")) { long long v = atoll(e); if (v > 0) budget = v; }   // tests force multi-batch frames with a small budget
+    long long t = budget / per_tile;
     if (t < 1) t = 1;
     out_tiles = (int)(t < tiles ? t : tiles);
     return RTX_OK;

@@ -1,0 +1,117 @@
+"""Unit-level parity of single reference functions evaluated on the device (C ABI debug hooks) and
+edge-case configurations of the whole path."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from pyrtx import api as a
+    a.load_library()
+    return a
+
+
+@pytest.mark.parametrize("name", ["materials_aniso", "materials_trilinear", "materials_ewa", "materials_bilinear"])
+def test_texture_sample_matches_reference_probes(api, name):
+    """Texture::sample (Texture.h:33-49) at 2 x 2048 seeded (s,t,derivative) inputs recorded from the REAL reference.
+    Bilinear / trilinear / anisotropic / EWA.  log2f (mip LOD) is evaluated in fp64 on the device, so a sample whose
+    LOD lands within 1 ulp of a level boundary could pick another level; none may exceed the tolerance here."""
+    sc, g = util.load_golden(name)
+    r = api.Renderer(sc)
+    # probe k was recorded on texture file k of the script: Floor.png then LEGOSHLD.tga; scene textures are in first-use order
+    sizes = [(int(t.desc["width"][0]), int(t.desc["height"][0])) for t in sc.textures]
+    for k, wh in enumerate([(32, 32), (256, 256)]):
+        probe = g[f"texprobe{k}"]
+        out = r.debug_texture_sample(sizes.index(wh), probe[:, :6])
+        d = np.abs(out.astype(np.float64) - probe[:, 6:9])
+        assert np.nanmax(d) < 1e-6, (name, k, float(np.nanmax(d)))
+        assert (d.max(axis=1) > 0).mean() < 0.02          # almost all samples are bit-exact
+
+
+def test_sky_sample_matches_oracle_bit_exact(api):
+    import ctypes as C
+    import orc
+    sc, _ = util.load_golden("cube")
+    r = api.Renderer(sc)
+    rng = np.random.RandomState(11)
+    d = rng.normal(size=(100000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    dev = r.debug_sky_sample(d)
+    o = orc.OracleScene(sc)
+    ref = np.zeros_like(d)
+    lib = orc.lib()
+    for i in range(0, len(d), 1):
+        lib.orc_sky_sample(o._sky.ctypes.data, o.struct.sky_size, d[i].ctypes.data, ref[i].ctypes.data)
+    assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("override", [{"traversal_strategy": 0}, {"texture_mode": 0}, {"bounces": 0}, {"bounces": 1}, {"bounces": 5},
+                                      {"stack_size": 40}, {"max_anisotropy": 2.0}])
+def test_config_knobs_vs_oracle(api, override):
+    """Every Config.h knob (Config.h:1-55) that changes the result: GPU vs oracle on the dielectric/texture scene."""
+    import orc
+    sc, _ = util.load_golden("materials_aniso")
+    for k, v in override.items():
+        sc.config[k] = v
+    if override.get("texture_mode", 2) != 2:
+        for t in sc.textures:
+            t.desc["mipmapped"] = 0; t.desc["mip_levels"] = 1
+    out = api.Renderer(sc).render()
+    ref = orc.OracleScene(sc).render(threads=8)
+    assert out["stats"] == ref["stats"], override
+    d = np.abs(out["rgb"].astype(np.float64) - ref["rgb"].astype(np.float64))
+    assert np.nanmax(d) < 1e-4 and np.array_equal(out["packed"], ref["packed"]), override
+
+
+def test_multi_batch_frame_equals_single_batch(api, monkeypatch):
+    """Deep recursion is rendered in tile batches bounded by the queue budget (plan_batch)."""
+    sc, _ = util.load_golden("materials_aniso")
+    full = api.Renderer(sc).render()
+    monkeypatch.setenv("RTX_SLOT_BUDGET", str(1024 * 15 * 7))      # 7 tiles per batch at depth 3
+    part = api.Renderer(sc).render()
+    assert np.array_equal(full["rgb"].view(np.uint32), part["rgb"].view(np.uint32)) and full["stats"] == part["stats"]
+
+
+def test_nan_from_beer_law_is_reproduced(api):
+    """Kt == 1 with a refracted ray that misses gives exp(0 * inf) = NaN in the reference (Raytracer.cpp:370-376)."""
+    import orc
+    sc, _ = util.load_golden("materials_aniso")
+    pm = int(sc.planes["material_id"][0])          # rays entering the (open) plane refract below it and hit nothing
+    sc.materials["transmittance"][pm] = (1.0, 1.0, 1.0); sc.materials["index_of_refraction"][pm] = 1.2
+    out = api.Renderer(sc).render()
+    ref = orc.OracleScene(sc).render(threads=8)
+    assert np.isnan(ref["rgb"]).any()
+    assert np.array_equal(np.isnan(out["rgb"]), np.isnan(ref["rgb"]))
+    m = ~np.isnan(ref["rgb"])
+    assert np.max(np.abs(out["rgb"][m] - ref["rgb"][m])) < 1e-4
+    assert np.array_equal(out["packed"], ref["packed"])
+
+
+def test_stack_overflow_is_reported_not_silent(api):
+    """A degenerate chain-shaped BVH deeper than RTX_MAX_STACK makes the reference smash its stack; here it is an error."""
+    from pyrtx import scene_io as sio
+    sc, _ = util.load_golden("cube")
+    depth = 80
+    nodes = np.zeros(2 + 2 * depth, sio.BVH_NODE)     # root 0, (unused 1), pairs (2d+2, 2d+3)
+    hot, cold = sc.blas[0].tri_hot[:1].copy(), sc.blas[0].tri_cold[:1].copy()
+    for d in range(depth):
+        k = 0 if d == 0 else 2 * d              # the LEFT child continues the chain: its right sibling (a leaf) waits on the stack
+        nodes[k]["aabb_min"] = -2; nodes[k]["aabb_max"] = 2
+        nodes[k]["left_or_first"] = 2 * d + 2; nodes[k]["count"] = 1 << 30
+        leaf = 2 * d + 3
+        nodes[leaf]["aabb_min"] = -2; nodes[leaf]["aabb_max"] = 2; nodes[leaf]["left_or_first"] = 0; nodes[leaf]["count"] = 1
+    last = 2 * depth
+    nodes[last]["aabb_min"] = -2; nodes[last]["aabb_max"] = 2; nodes[last]["left_or_first"] = 0; nodes[last]["count"] = 1
+    sc.blas[0] = sio.Blas(nodes, hot, cold, sc.blas[0].material_offset, 1)
+    sc.config["traversal_strategy"] = 0          # naive: always left first
+    r = api.Renderer(sc)
+    r.render_async()
+    with pytest.raises(api.RtxError) as e:
+        r.stats()
+    assert e.value.code == 4
