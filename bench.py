@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--simple-trace", action="store_true", help="A/B: plain pop-and-test traversal kernels")
+    ap.add_argument("--cull", action="store_true", help="time with RTX_RENDER_CULL_DEAD_SHADOW_RAYS as the main figure (default: reported as an extra)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,7 +99,7 @@ def main():
     gather = shard.TileGather(W, H, rank, world, "cuda") if world > 1 else None
 
     def step():
-        r.render_async(first, stride, count, simple_trace=args.simple_trace)
+        r.render_async(first, stride, count, simple_trace=args.simple_trace, cull_dead_shadow_rays=args.cull)
         if gather is not None:
             gather(fb_packed)
 
@@ -128,6 +129,19 @@ def main():
     t1 = time.perf_counter()
     ktimes = r.kernel_times()
     r.enable_timing(False)
+    # extra (not the headline): the same frame with dead shadow rays counted but not traversed
+    t_cull = None
+    if world == 1 and not args.cull and not args.simple_trace:
+        for _ in range(2):
+            r.render_async(first, stride, count, cull_dead_shadow_rays=True)
+        sync()
+        tc0 = time.perf_counter()
+        for _ in range(args.steps):
+            r.render_async(first, stride, count, cull_dead_shadow_rays=True)
+        sync()
+        t_cull = 1000.0 * (time.perf_counter() - tc0) / max(args.steps, 1)
+        r.render_async(first, stride, count)          # leave the un-culled frame in the framebuffer for the parity check
+        sync()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -171,6 +185,7 @@ def main():
             "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3], "total": tot[4]},
             "mprimary_per_s": round(tot[0] / (ms_per_step * 1e-3) * 1e-6, 3),
             "kernels": kern,
+            "extra_cull_dead_shadow_rays": None if t_cull is None else {"ms_per_step": round(t_cull, 4), "note": "RTX_RENDER_CULL_DEAD_SHADOW_RAYS: identical frame and ray counts; shadow rays with an exactly-zero light contribution are counted but not traversed"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": None if achieved is None else round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / 8000.0, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_frame / max(launches_per_frame, 1)),

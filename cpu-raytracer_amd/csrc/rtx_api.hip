@@ -392,6 +392,7 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
     hipSetDevice(c->cfg.device);
     const bool count_work = (flags & RTX_RENDER_COUNT_WORK) != 0;
     const bool simple = (flags & RTX_RENDER_SIMPLE_TRACE) != 0;
+    const bool cull = (flags & RTX_RENDER_CULL_DEAD_SHADOW_RAYS) != 0 && !simple && !count_work;
 
     // stats of this call: reset accumulators (WorkerThread.cpp:120 zeroes them per frame)
     HIP_OK(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), c->stream));
@@ -417,8 +418,9 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
                 else              hipLaunchKernelGGL((k_trace_fast<false>),   dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
             });
             launch_timed(c, "k_shade", [&] {
-                if (count_work) hipLaunchKernelGGL((k_shade<true>),  dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
-                else            hipLaunchKernelGGL((k_shade<false>), dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
+                if (count_work) hipLaunchKernelGGL((k_shade<true, false>),  dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
+                else if (cull)  hipLaunchKernelGGL((k_shade<false, true>),  dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
+                else            hipLaunchKernelGGL((k_shade<false, false>), dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
             });
             if (sc.light_count > 0) launch_timed(c, "k_trace_any", [&] {
                 if (count_work)   hipLaunchKernelGGL((k_trace<true, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);

@@ -141,7 +141,11 @@ RTX_D v3 light_calc(v3 colour, v3 normal, v3 to_light, v3 to_camera) {
     return vmuls(colour, intensity);
 }
 
-template <bool COUNT>
+// CULL: a light whose unshadowed contribution is exactly (0,0,0) (N.L <= 0, Light.h:17-18, or outside the spot cone,
+// SpotLight.h:25-26) cannot change the pixel whether or not it is occluded (diffuse + 0 == diffuse).  With CULL the shadow
+// ray is still COUNTED (the reference counts before testing, Raytracer.cpp:163,180,192) but marked so that k_trace<any>
+// retires it without traversal.  Off by default; bench.py reports it as a separate figure.
+template <bool COUNT, bool CULL>
 __global__ __launch_bounds__(RTX_SHADE_BLOCK)
 void k_shade(const DevScene sc, const DevQueues q, const int level) {
     DevCounters * const ctr = q.counters;
@@ -239,9 +243,11 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
                 to_light = vdivs(to_light, d);
                 const v3 c = vdivs(light_calc(v3p(pl.colour), h.normal, to_light, to_camera), d2);   // PointLight.h:9-11
                 const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
-                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, d);
+                const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
+                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : d);
                 q.s1[s] = make_float4(to_light.x, to_light.y, to_light.z, 0.0f);
                 q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
+                if (dead) q.socc[s] = 1u;
             }
             for (int i = 0; i < sc.spot_light_count; i++, L++) {                  // :172-186
                 const rtx_spot_light & sl = sc.spot_lights[i];
@@ -257,18 +263,22 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
                     c = vmuls(vdivs(light_calc(v3p(sl.colour), h.normal, to_light, to_camera), d2), falloff);
                 }
                 const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
-                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, d);
+                const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
+                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : d);
                 q.s1[s] = make_float4(to_light.x, to_light.y, to_light.z, 0.0f);
                 q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
+                if (dead) q.socc[s] = 1u;
             }
             for (int i = 0; i < sc.dir_light_count; i++, L++) {                   // :189-198
                 const rtx_directional_light & dl = sc.dir_lights[i];
                 const v3 nd = v3p(dl.negative_direction);
                 const v3 c = light_calc(v3p(dl.colour), h.normal, nd, to_camera);
                 const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
-                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, INFINITY);
+                const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
+                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : INFINITY);
                 q.s1[s] = make_float4(nd.x, nd.y, nd.z, 0.0f);
                 q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
+                if (dead) q.socc[s] = 1u;
             }
             n_shadow += (uint32_t)nL;                                             // counted before the occlusion test (:163,180,192)
         }

@@ -388,6 +388,7 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level) {
                     out_slot = (uint32_t)q.shadow_base[level] + light * (uint32_t)lit_cap + rank;
                     const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot];
                     wo = V3(s0.x, s0.y, s0.z); tcur = s0.w; wd = V3(s1.x, s1.y, s1.z);
+                    if (tcur < 0.0f) live = false;        // culled by k_shade<.., CULL>: contribution is exactly zero, already resolved
                 } else {
                     out_slot = (uint32_t)q.level_base[level] + idx;
                     if (level == 0) {

@@ -135,3 +135,14 @@ def test_atrium_cfg3_small_matches_oracle(api):
     d = np.abs(out["rgb"].astype(np.float64) - ref["rgb"].astype(np.float64))
     assert np.nanmax(d) < TOL
     assert np.array_equal(out["packed"], ref["packed"])
+
+
+@pytest.mark.parametrize("name", ["materials_aniso", "dynamic", "tori16", "monkey_small"])
+def test_culling_dead_shadow_rays_changes_nothing(api, name):
+    """RTX_RENDER_CULL_DEAD_SHADOW_RAYS: frame and PerformanceStats are bit-identical with the flag on."""
+    sc, _ = util.load_golden(name)
+    r = api.Renderer(sc)
+    a = r.render()
+    b = r.render(cull_dead_shadow_rays=True)
+    assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    assert np.array_equal(a["packed"], b["packed"]) and a["stats"] == b["stats"]
