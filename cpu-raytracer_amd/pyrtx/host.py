@@ -155,11 +155,26 @@ def texture_with_mips(level0_rgb: np.ndarray) -> sio.Texture:
     return sio.Texture(d, buf[:cnt.value].copy())
 
 
-def gamma_to_linear(x: np.ndarray) -> np.ndarray:
-    """Math::gamma_to_linear, Math.h:78-88 (used by Texture::load, Texture.cpp:64-72)."""
-    x = np.asarray(x, np.float32)
-    lin = np.where(x < np.float32(0.04045), x / np.float32(12.92), np.power((x + np.float32(0.055)) / np.float32(1.055), np.float32(2.4), dtype=np.float32))
-    return np.clip(np.where(x <= 0, 0, np.where(x >= 1, 1, lin)), 0, 1).astype(np.float32)
+_SRGB_LUT = None
+
+
+def srgb8_to_linear(img_u8: np.ndarray) -> np.ndarray:
+    """Texture::load's decode (Texture.cpp:13-20,64-72): byte * 0.00392156862f, then Math::gamma_to_linear
+    (Math.h:78-88) with the host libm's powf — evaluated once per byte value into a 256-entry table."""
+    global _SRGB_LUT
+    if _SRGB_LUT is None:
+        libm = C.CDLL("libm.so.6")
+        libm.powf.restype = C.c_float; libm.powf.argtypes = [C.c_float, C.c_float]
+        lut = np.zeros(256, np.float32)
+        for b in range(256):
+            x = np.float32(b) * np.float32(0.00392156862)
+            if x <= 0: v = np.float32(0.0)
+            elif x >= 1: v = np.float32(1.0)
+            elif x < np.float32(0.04045): v = x / np.float32(12.92)
+            else: v = np.float32(libm.powf(float((x + np.float32(0.055)) / np.float32(1.055)), 2.4))
+            lut[b] = v
+        _SRGB_LUT = lut
+    return _SRGB_LUT[img_u8]
 
 
 def synthetic_sky(n: int = 64) -> np.ndarray:
@@ -173,7 +188,8 @@ def synthetic_sky(n: int = 64) -> np.ndarray:
     return sky
 
 
-def _procedural_textures(seed: int) -> List[sio.Texture]:
+def procedural_texture_images(seed: int) -> List[np.ndarray]:
+    """The cfg3 stand-in's four power-of-two textures as 8-bit sRGB images (h, w, 3) — the form an asset file has."""
     rng = np.random.RandomState(seed & 0x7fffffff)
 
     def noise(n, octaves=4):
@@ -205,7 +221,11 @@ def _procedural_textures(seed: int) -> List[sio.Texture]:
     y, x = np.mgrid[0:n, 0:n]
     f = 0.6 + 0.3 * np.sin(x * (2 * np.pi / 16)).astype(np.float32) + 0.08 * noise(n)
     texs.append(np.stack([f, f, f], -1))
-    return [texture_with_mips(gamma_to_linear(np.clip(t, 0, 1).astype(np.float32))) for t in texs]
+    return [np.clip(np.rint(np.clip(t, 0, 1) * 255.0), 0, 255).astype(np.uint8) for t in texs]
+
+
+def _procedural_textures(seed: int) -> List[sio.Texture]:
+    return [texture_with_mips(srgb8_to_linear(img)) for img in procedural_texture_images(seed)]
 
 
 def make_config(width, height, bounces, mip_filter=1, texture_mode=2, stack_size=64, traversal=1, max_aniso=8.0) -> np.ndarray:
@@ -216,10 +236,14 @@ def make_config(width, height, bounces, mip_filter=1, texture_mode=2, stack_size
     return cfg
 
 
-def atrium_scene(width: int = 1920, height: int = 1080, bounces: int = 3, detail: int = 1, seed: int = 0x5EED0003,
-                 mip_filter: int = 1, bins: int = 32) -> sio.Scene:
-    """BASELINE.json configs[2]: Sponza-class (255 296 triangles at detail 1) stand-in, 3 lights,
-    reflect/refract depth 3, anisotropic mip filter (the shipped default, Config.h:53)."""
+ATRIUM_CAMERA = ((24.0, 5.5, 1.2), ((0.0, 1.0, 0.0), -1.45))     # position, (axis, angle)
+ATRIUM_POINT = ((30.0, 26.0, 20.0), (-6.0, 9.0, 0.5))            # colour, position
+ATRIUM_SPOT = ((40.0, 40.0, 48.0), (20.0, 14.0, -2.0), (-0.8, -0.55, 0.25), 50.0, 70.0)   # colour, position, direction, inner, outer (degrees)
+ATRIUM_DIR = ((0.9, 0.9, 0.9), (0.1, -1.0, 0.1))                 # Scene.cpp:125
+
+
+def atrium_mesh(seed: int = 0x5EED0003, detail: int = 1):
+    """(positions (n,3,3), normals (n,3,3), texcoords (n,3,2) [v already flipped], material ids (n,), material count)."""
     mesh = RtxhMesh()
     assert lib().rtxh_atrium_generate(seed, detail, C.byref(mesh)) == 0
     n = mesh.triangle_count
@@ -229,20 +253,18 @@ def atrium_scene(width: int = 1920, height: int = 1080, bounces: int = 3, detail
     mid = np.ctypeslib.as_array(mesh.material_ids, (n,)).copy()
     nmat = mesh.material_count
     lib().rtxh_mesh_free(C.byref(mesh))
+    return pos, nrm, uv, mid, nmat
 
-    sc = sio.Scene()
-    sc.config = make_config(width, height, bounces, mip_filter=mip_filter)
-    sc.textures = _procedural_textures(seed)
-    # material table: 0 = MaterialBuffer default (Material.h:52-60), then the mesh's materials (sponza.mtl-like Kd ~0.47)
-    mats = np.zeros(1 + nmat, sio.MATERIAL)
-    mats["texture_id"] = -1; mats["index_of_refraction"] = 1.0
-    m = mats[1:]
+
+def atrium_materials(nmat: int) -> np.ndarray:
+    """25 mesh-local materials mimicking sponza.mtl (Kd ~0.47, a few with Ks / Kt), texture ids into procedural_texture_images."""
+    m = np.zeros(nmat, sio.MATERIAL)
+    m["texture_id"] = -1; m["index_of_refraction"] = 1.0
     m["diffuse"] = 0.4704
     kd = {0: (0.75, 0.75, 0.75), 1: (0.8, 0.8, 0.8), 2: (0.7, 0.68, 0.6), 3: (0.8, 0.78, 0.74), 4: (0.6, 0.58, 0.5), 5: (0.75, 0.73, 0.7), 6: (0.5, 0.47, 0.4)}
     for k, v in kd.items():
         m["diffuse"][k] = v
-    tex = {0: 0, 1: 1, 2: 1, 3: 2, 4: 2, 5: 2, 6: 2}
-    for k, v in tex.items():
+    for k, v in {0: 0, 1: 1, 2: 1, 3: 2, 4: 2, 5: 2, 6: 2}.items():
         m["texture_id"][k] = v
     m["reflection"][0] = (0.15, 0.15, 0.15)                       # polished floor
     curtain = [(0.7, 0.1, 0.1), (0.1, 0.5, 0.15), (0.1, 0.15, 0.7), (0.7, 0.6, 0.1), (0.6, 0.1, 0.6), (0.1, 0.6, 0.6)]
@@ -256,6 +278,21 @@ def atrium_scene(width: int = 1920, height: int = 1080, bounces: int = 3, detail
     for i in range(4):                                               # statues: bronze-ish
         m["diffuse"][17 + i] = (0.45 - 0.05 * i, 0.3, 0.15 + 0.04 * i); m["reflection"][17 + i] = (0.12, 0.1, 0.06)
     m["diffuse"][21] = (0.35, 0.3, 0.25); m["diffuse"][22] = (0.6, 0.6, 0.6); m["diffuse"][23] = (0.85, 0.85, 0.8); m["diffuse"][24] = (0.5, 0.5, 0.5)
+    return m
+
+
+def atrium_scene(width: int = 1920, height: int = 1080, bounces: int = 3, detail: int = 1, seed: int = 0x5EED0003,
+                 mip_filter: int = 1, bins: int = 32) -> sio.Scene:
+    """BASELINE.json configs[2]: Sponza-class (255 296 triangles at detail 1) stand-in, 3 lights,
+    reflect/refract depth 3, anisotropic mip filter (the shipped default, Config.h:53)."""
+    pos, nrm, uv, mid, nmat = atrium_mesh(seed, detail)
+    sc = sio.Scene()
+    sc.config = make_config(width, height, bounces, mip_filter=mip_filter)
+    sc.textures = _procedural_textures(seed)
+    # material table: 0 = MaterialBuffer default (Material.h:52-60), then the mesh's materials
+    mats = np.zeros(1 + nmat, sio.MATERIAL)
+    mats["texture_id"] = -1; mats["index_of_refraction"] = 1.0
+    mats[1:] = atrium_materials(nmat)
     sc.materials = mats
     sc.blas = [build_blas(pos, nrm, uv, mid, material_offset=1, bins=bins)]
     root = sc.blas[0].nodes[0]
@@ -264,15 +301,18 @@ def atrium_scene(width: int = 1920, height: int = 1080, bounces: int = 3, detail
     tl = Tlas(1)
     sc.tlas_nodes, sc.tlas_indices = tl.build(np.zeros((1, 3), np.float32), np.concatenate([mn, mx])[None])
     sc.sky = synthetic_sky()
-    # 3 lights: the shipped directional light (Scene.cpp:125), one point, one spot
-    d = np.array([0.1, -1.0, 0.1], np.float32); d = d / np.sqrt((d * d).sum(dtype=np.float32), dtype=np.float32)
-    sc.dir_lights = np.zeros(1, sio.DIR_LIGHT); sc.dir_lights["colour"] = 0.9; sc.dir_lights["negative_direction"] = -d
-    sc.point_lights = np.zeros(1, sio.POINT_LIGHT); sc.point_lights["colour"] = (30.0, 26.0, 20.0); sc.point_lights["position"] = (-6.0, 9.0, 0.5)
-    sd = np.array([-0.8, -0.55, 0.25], np.float32); sd = sd / np.sqrt((sd * sd).sum(dtype=np.float32), dtype=np.float32)
-    sc.spot_lights = np.zeros(1, sio.SPOT_LIGHT); sc.spot_lights["colour"] = (40.0, 40.0, 48.0); sc.spot_lights["position"] = (20.0, 14.0, -2.0)
-    sc.spot_lights["negative_direction"] = -sd
-    sc.spot_lights["inner_cutoff"] = np.cos(np.float32(0.5 * 50.0) * PI * np.float32(0.00555555555), dtype=np.float32)   # DEG_TO_RAD, Util.h:14
-    sc.spot_lights["outer_cutoff"] = np.cos(np.float32(0.5 * 70.0) * PI * np.float32(0.00555555555), dtype=np.float32)
-    fov = float(np.float32(110.0) * PI * np.float32(0.00555555555))                                                       # Scene.cpp:75
-    sc.camera = camera_basis(width, height, fov, (24.0, 5.5, 1.2), axis_angle((0, 1, 0), -1.45))
+
+    def normalize(v):                                                # Vector3::normalize, Vector3.h:24-31
+        v = np.asarray(v, np.float32)
+        inv = np.float32(1.0) / np.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2], dtype=np.float32)
+        return v * inv
+    deg2rad = lambda a: np.float32(a) * PI * np.float32(0.00555555555)   # DEG_TO_RAD, Util.h:14
+    sc.dir_lights = np.zeros(1, sio.DIR_LIGHT); sc.dir_lights["colour"] = ATRIUM_DIR[0]; sc.dir_lights["negative_direction"] = -normalize(ATRIUM_DIR[1])
+    sc.point_lights = np.zeros(1, sio.POINT_LIGHT); sc.point_lights["colour"] = ATRIUM_POINT[0]; sc.point_lights["position"] = ATRIUM_POINT[1]
+    sc.spot_lights = np.zeros(1, sio.SPOT_LIGHT); sc.spot_lights["colour"] = ATRIUM_SPOT[0]; sc.spot_lights["position"] = ATRIUM_SPOT[1]
+    sc.spot_lights["negative_direction"] = -normalize(ATRIUM_SPOT[2])
+    sc.spot_lights["inner_cutoff"] = np.cos(deg2rad(np.float32(0.5) * np.float32(ATRIUM_SPOT[3])), dtype=np.float32)      # SpotLight.h:13-14
+    sc.spot_lights["outer_cutoff"] = np.cos(deg2rad(np.float32(0.5) * np.float32(ATRIUM_SPOT[4])), dtype=np.float32)
+    fov = float(deg2rad(110.0))                                                                                              # Scene.cpp:75
+    sc.camera = camera_basis(width, height, fov, ATRIUM_CAMERA[0], axis_angle(*ATRIUM_CAMERA[1]))
     return sc
