@@ -17,6 +17,9 @@
 #include "rtx_trace.h"
 
 #define RTX_SHADE_BLOCK 256
+#ifndef RTX_WAVES_SHADE
+#define RTX_WAVES_SHADE 1     // __launch_bounds__ min waves per SIMD for k_shade
+#endif
 
 struct HitFull {          // RayHit, RayHit.h:4-36
     v3 point, normal;
@@ -146,7 +149,7 @@ RTX_D v3 light_calc(v3 colour, v3 normal, v3 to_light, v3 to_camera) {
 // ray is still COUNTED (the reference counts before testing, Raytracer.cpp:163,180,192) but marked so that k_trace<any>
 // retires it without traversal.  Off by default; bench.py reports it as a separate figure.
 template <bool COUNT, bool CULL>
-__global__ __launch_bounds__(RTX_SHADE_BLOCK)
+__global__ __launch_bounds__(RTX_SHADE_BLOCK, RTX_WAVES_SHADE)
 void k_shade(const DevScene sc, const DevQueues q, const int level) {
     DevCounters * const ctr = q.counters;
     const uint32_t count = ctr->ray_count[level];
