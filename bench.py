@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--simple-trace", action="store_true", help="A/B: plain pop-and-test traversal kernels")
+    ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather plumbing even with one rank (single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--cull", action="store_true", help="time with RTX_RENDER_CULL_DEAD_SHADOW_RAYS as the main figure (default: reported as an extra)")
     args = ap.parse_args()
 
@@ -96,7 +97,10 @@ def main():
     first, stride, count = shard.shard_args(T, rank, world)     # tile t belongs to GPU t mod N
 
     # ---- gather plumbing (N > 1): each rank sends only the pixels of its own tiles ---------------------
-    gather = shard.TileGather(W, H, rank, world, "cuda") if world > 1 else None
+    if args.force_gather and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    gather = shard.TileGather(W, H, rank, world, "cuda") if (world > 1 or args.force_gather) else None
 
     def step():
         r.render_async(first, stride, count, simple_trace=args.simple_trace, cull_dead_shadow_rays=args.cull)
@@ -131,7 +135,7 @@ def main():
     r.enable_timing(False)
     # extra (not the headline): the same frame with dead shadow rays counted but not traversed
     t_cull = None
-    if world == 1 and not args.cull and not args.simple_trace:
+    if world == 1 and not args.cull and not args.simple_trace and gather is None:
         for _ in range(2):
             r.render_async(first, stride, count, cull_dead_shadow_rays=True)
         sync()
@@ -142,6 +146,12 @@ def main():
         t_cull = 1000.0 * (time.perf_counter() - tc0) / max(args.steps, 1)
         r.render_async(first, stride, count)          # leave the un-culled frame in the framebuffer for the parity check
         sync()
+    # the gathered frame on rank 0 must equal a frame rendered by rank 0 alone (untimed check)
+    gather_ok = None
+    if gather is not None and rank == 0:
+        r.render_async(0, 1, T)
+        torch.cuda.synchronize()
+        gather_ok = bool(torch.equal(gather.final, fb_packed))
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -185,6 +195,7 @@ def main():
             "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3], "total": tot[4]},
             "mprimary_per_s": round(tot[0] / (ms_per_step * 1e-3) * 1e-6, 3),
             "kernels": kern,
+            "gathered_frame_equals_single_gpu_frame": gather_ok,
             "extra_cull_dead_shadow_rays": None if t_cull is None else {"ms_per_step": round(t_cull, 4), "note": "RTX_RENDER_CULL_DEAD_SHADOW_RAYS: identical frame and ray counts; shadow rays with an exactly-zero light contribution are counted but not traversed"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": None if achieved is None else round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / 8000.0, 5), "traffic": traffic,
@@ -214,7 +225,7 @@ def main():
                              "packed_mismatch": int((fb_packed.cpu().numpy().view(np.uint32).reshape(H, W) != ref["packed"]).sum()),
                              "stats_equal": ref["stats"] == stats}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

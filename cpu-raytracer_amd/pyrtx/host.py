@@ -142,6 +142,34 @@ def build_blas(positions: np.ndarray, normals: np.ndarray, texcoords: np.ndarray
     return sio.Blas(nodes[:nc.value].copy(), hot, cold, material_offset, n)
 
 
+def load_bvh_cache(path: str, material_offset: int = 0) -> sio.Blas:
+    """Reads a `<mesh>.obj.bvh` file exactly as BottomLevelBVH::load_from_disk does (BottomLevelBVH.cpp:171-192:
+    int triangle_count; TriangleHot[n]; TriangleCold[n]; int node_count; BVHNode[node_count]; int index_count; int[index_count])
+    and applies BottomLevelBVH::flatten (:196-212).  The record layouts are the C ABI's, so no conversion happens."""
+    buf = open(path, "rb").read()
+    n = int(np.frombuffer(buf, np.int32, 1, 0)[0]); off = 4
+    hot = np.frombuffer(buf, sio.TRI_HOT, n, off); off += n * sio.TRI_HOT.itemsize
+    cold = np.frombuffer(buf, sio.TRI_COLD, n, off); off += n * sio.TRI_COLD.itemsize
+    nc = int(np.frombuffer(buf, np.int32, 1, off)[0]); off += 4
+    nodes = np.frombuffer(buf, sio.BVH_NODE, nc, off).copy(); off += nc * sio.BVH_NODE.itemsize
+    ic = int(np.frombuffer(buf, np.int32, 1, off)[0]); off += 4
+    idx = np.frombuffer(buf, np.int32, ic, off)
+    assert off + 4 * ic == len(buf), "trailing bytes in .bvh cache"
+    if nc > 1:
+        nodes[1] = np.zeros(1, sio.BVH_NODE)[0]           # never written by the reference (uninitialised heap in the file)
+    return sio.Blas(nodes, hot[idx].copy(), cold[idx].copy(), material_offset, n)
+
+
+def save_bvh_cache(path: str, blas: sio.Blas) -> None:
+    """Writes a flattened BLAS in the reference's `.bvh` layout (BottomLevelBVH.cpp:149-168) with an identity index list,
+    so the reference's load_from_disk + flatten reproduce the same arrays."""
+    n = len(blas.tri_hot)
+    with open(path, "wb") as f:
+        f.write(np.int32(n).tobytes()); f.write(np.ascontiguousarray(blas.tri_hot).tobytes()); f.write(np.ascontiguousarray(blas.tri_cold).tobytes())
+        f.write(np.int32(len(blas.nodes)).tobytes()); f.write(np.ascontiguousarray(blas.nodes).tobytes())
+        f.write(np.int32(n).tobytes()); f.write(np.arange(n, dtype=np.int32).tobytes())
+
+
 def texture_with_mips(level0_rgb: np.ndarray) -> sio.Texture:
     """level0_rgb: (h, w, 3) linear-space float32 -> Texture with the reference's box-filter chain."""
     h, w, _ = level0_rgb.shape

@@ -146,3 +146,15 @@ def test_culling_dead_shadow_rays_changes_nothing(api, name):
     b = r.render(cull_dead_shadow_rays=True)
     assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
     assert np.array_equal(a["packed"], b["packed"]) and a["stats"] == b["stats"]
+
+
+def test_bench_gather_path_on_one_gpu():
+    """bench.py's N>1 plumbing (tile shard -> index_select -> RCCL gather -> un-swizzle) rehearsed with one rank over nccl."""
+    import json, os, subprocess, sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(util.REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "materials",
+                          "--cpu-seconds", "0", "--force-gather"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["gathered_frame_equals_single_gpu_frame"] is True
+    assert j["rays_per_frame"]["total"] == 57600 + 191709 + 52955 + 12692

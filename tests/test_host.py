@@ -89,3 +89,19 @@ def test_atrium_scene_is_deterministic_and_renders_on_the_oracle():
     out = orc.OracleScene(a).render(threads=8)
     assert out["stats"]["primary"] == 160 * 90 and out["stats"]["shadow"] > 0 and out["stats"]["reflection"] > 0 and out["stats"]["refraction"] > 0
     assert not np.isnan(out["rgb"]).any()
+
+
+@pytest.mark.parametrize("mesh,golden,blas_index", [("Cube", "cube", 0), ("Torus", "tori16_f1", 0)])
+def test_reference_bvh_cache_files_load_unchanged(mesh, golden, blas_index, tmp_path):
+    """`.obj.bvh` files WRITTEN BY THE REAL REFERENCE (BottomLevelBVH::save_to_disk, committed as data under
+    tests/golden/bvh_cache) load through host.load_bvh_cache into exactly the BLAS the reference traversed."""
+    import os
+    sc, _ = util.load_golden(golden)
+    ref = sc.blas[blas_index]
+    b = host.load_bvh_cache(os.path.join(util.GOLDEN, "bvh_cache", mesh + ".obj.bvh"), ref.material_offset)
+    assert b.nodes.tobytes() == ref.nodes.tobytes()
+    assert b.tri_hot.tobytes() == ref.tri_hot.tobytes() and b.tri_cold.tobytes() == ref.tri_cold.tobytes()
+    # writer -> reader round trip
+    host.save_bvh_cache(str(tmp_path / "x.bvh"), b)
+    c = host.load_bvh_cache(str(tmp_path / "x.bvh"), ref.material_offset)
+    assert c.nodes.tobytes() == b.nodes.tobytes() and c.tri_hot.tobytes() == b.tri_hot.tobytes() and c.tri_cold.tobytes() == b.tri_cold.tobytes()
