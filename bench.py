@@ -42,6 +42,13 @@ def algorithmic_bytes_any(work):
             + 36 * work["tri_tests_any"] + 32 * work["any_rays"])
 
 
+def _group(times):
+    g = {}
+    for name, ms in times:
+        g.setdefault(name, []).append(ms)
+    return g
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,7 +60,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--simple-trace", action="store_true", help="A/B: plain pop-and-test traversal kernels")
+    ap.add_argument("--simulate-ranks", type=int, default=0, help="single-GPU rehearsal: render only the tile shard rank 0 of N would own (no gather)")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather plumbing even with one rank (single-GPU rehearsal of the N>1 path)")
+    ap.add_argument("--serial", action="store_true", help="RTX_RENDER_SERIAL for the timed loop (no overlap of shadow-ray kernels)")
     ap.add_argument("--cull", action="store_true", help="time with RTX_RENDER_CULL_DEAD_SHADOW_RAYS as the main figure (default: reported as an extra)")
     args = ap.parse_args()
 
@@ -95,6 +104,8 @@ def main():
 
     T = sc.tile_count
     first, stride, count = shard.shard_args(T, rank, world)     # tile t belongs to GPU t mod N
+    if args.simulate_ranks > 1 and world == 1:
+        first, stride, count = shard.shard_args(T, 0, args.simulate_ranks)
 
     # ---- gather plumbing (N > 1): each rank sends only the pixels of its own tiles ---------------------
     if args.force_gather and world == 1:
@@ -103,7 +114,7 @@ def main():
     gather = shard.TileGather(W, H, rank, world, "cuda") if (world > 1 or args.force_gather) else None
 
     def step():
-        r.render_async(first, stride, count, simple_trace=args.simple_trace, cull_dead_shadow_rays=args.cull)
+        r.render_async(first, stride, count, simple_trace=args.simple_trace, cull_dead_shadow_rays=args.cull, serial=args.serial)
         if gather is not None:
             gather(fb_packed)
 
@@ -146,6 +157,15 @@ def main():
         t_cull = 1000.0 * (time.perf_counter() - tc0) / max(args.steps, 1)
         r.render_async(first, stride, count)          # leave the un-culled frame in the framebuffer for the parity check
         sync()
+    # extra: per-kernel durations with every kernel on one stream (no overlap between shadow-ray and closest-hit kernels)
+    serial_times = None
+    if world == 1 and gather is None:
+        r.enable_timing(True)
+        for _ in range(min(args.steps, 10)):
+            r.render_async(first, stride, count, serial=True)
+        sync()
+        serial_times = r.kernel_times()
+        r.enable_timing(False)
     # the gathered frame on rank 0 must equal a frame rendered by rank 0 alone (untimed check)
     gather_ok = None
     if gather is not None and rank == 0:
@@ -169,13 +189,14 @@ def main():
                "k_trace_any": (algorithmic_bytes_any(work), work["any_rays"])}
         for k, (b, n) in alg.items():
             if k in kern:
-                # one launch per level and frame: bytes per launch = bytes per frame / levels
-                kern[k]["algorithmic_GBps"] = round((b / levels) / (kern[k]["avg_ms"] * 1e-3) / 1e9, 2)
-                kern[k]["Grays_per_s"] = round((n / levels) / (kern[k]["avg_ms"] * 1e-3) / 1e9, 4)
+                lpf = kern[k]["launches"] / max(args.steps, 1)          # launches per frame (closest: one per level; any: level 0 + levels 1..D)
+                kern[k]["launches_per_frame"] = lpf
+                kern[k]["algorithmic_GBps"] = round((b / lpf) / (kern[k]["avg_ms"] * 1e-3) / 1e9, 2)
+                kern[k]["Grays_per_s"] = round((n / lpf) / (kern[k]["avg_ms"] * 1e-3) / 1e9, 4)
                 kern[k]["bytes_per_ray"] = round(b / max(n, 1), 1)
         dom = max((k for k in alg if k in kern), key=lambda k: kern[k]["total_ms_per_step"], default="k_trace_closest")
         bytes_frame = alg[dom][0]
-        launches_per_frame = levels
+        launches_per_frame = kern[dom]["launches_per_frame"] if dom in kern else levels
         avg_s = kern[dom]["avg_ms"] * 1e-3 if dom in kern else float("nan")
         achieved = (bytes_frame / launches_per_frame) / avg_s / 1e9 if dom in kern else None
         traffic = None
@@ -196,6 +217,8 @@ def main():
             "mprimary_per_s": round(tot[0] / (ms_per_step * 1e-3) * 1e-6, 3),
             "kernels": kern,
             "gathered_frame_equals_single_gpu_frame": gather_ok,
+            "kernels_serial_mode": None if not serial_times else {k: {"launches_per_frame": len(v) / min(args.steps, 10), "avg_ms": round(float(np.mean(v)), 5), "total_ms_per_frame": round(float(np.sum(v)) / min(args.steps, 10), 4)}
+                                                                    for k, v in _group(serial_times).items()},
             "extra_cull_dead_shadow_rays": None if t_cull is None else {"ms_per_step": round(t_cull, 4), "note": "RTX_RENDER_CULL_DEAD_SHADOW_RAYS: identical frame and ray counts; shadow rays with an exactly-zero light contribution are counted but not traversed"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": None if achieved is None else round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / 8000.0, 5), "traffic": traffic,

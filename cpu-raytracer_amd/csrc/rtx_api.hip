@@ -37,6 +37,8 @@ struct rtx_ctx {
     rtx_config cfg;
     hipStream_t stream = nullptr;        // stream all work is enqueued on
     hipStream_t own_stream = nullptr;    // created by rtx_create
+    hipStream_t any_stream = nullptr;    // shadow-ray kernels run here, overlapping the next levels' closest-hit / shade kernels
+    hipEvent_t ev_shade0 = nullptr, ev_shade_last = nullptr, ev_any_done = nullptr;
     void * ext_rgb = nullptr, * ext_packed = nullptr;
     std::string err;
     int n_cu = 0;
@@ -63,6 +65,7 @@ struct rtx_ctx {
     std::vector<DevCounters *> pending_host;   // pinned copies, one per batch
 
     bool timing = false;
+    bool serial = false;                 // RTX_RENDER_SERIAL: keep every kernel on one stream (per-kernel timings without overlap)
     std::vector<KernelTime> times;
     std::vector<hipEvent_t> event_pool;
     size_t event_next = 0;
@@ -125,6 +128,9 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RTX_ERR_HIP; }
     c->stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->any_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RTX_ERR_HIP; }
+    hipEventCreateWithFlags(&c->ev_shade0, hipEventDisableTiming); hipEventCreateWithFlags(&c->ev_shade_last, hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->ev_any_done, hipEventDisableTiming);
 
     // Texture::init(alpha = 2) EWA weight table, Texture.h:53-62 (host libm, like the reference; shipped as data)
     float ewa[RTX_EWA_LUT_SIZE];
@@ -179,6 +185,10 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     for (DevBuf & b : c->qb) if (b.p) hipFree(b.p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     for (DevCounters * h : c->pending_host) hipHostFree(h);
+    if (c->any_stream) { hipStreamSynchronize(c->any_stream); hipStreamDestroy(c->any_stream); }
+    if (c->ev_shade0) hipEventDestroy(c->ev_shade0);
+    if (c->ev_shade_last) hipEventDestroy(c->ev_shade_last);
+    if (c->ev_any_done) hipEventDestroy(c->ev_any_done);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return RTX_OK;
@@ -362,10 +372,11 @@ static int alloc_queues(rtx_ctx * c, int batch_tiles) {
     return rc;
 }
 
-__global__ void k_begin_batch(DevCounters * ctr, uint32_t primary_slots) {
-    // zero everything except the accumulating stats / work counters and the error flags
+__global__ void k_begin_batch(DevCounters * ctr, uint32_t primary_slots, uint32_t closest_threads, uint32_t any_threads) {
+    // zero everything except the accumulating stats / work counters and the error flags; the dynamic-fetch heads start
+    // behind the statically assigned first round (one ray per resident thread)
     const int i = threadIdx.x;
-    if (i <= RTX_MAX_LEVELS) { ctr->ray_count[i] = (i == 0) ? primary_slots : 0u; ctr->lit_count[i] = 0u; ctr->fetch_closest[i] = 0u; ctr->fetch_any[i] = 0u; }
+    if (i <= RTX_MAX_LEVELS) { ctr->ray_count[i] = (i == 0) ? primary_slots : 0u; ctr->lit_count[i] = 0u; ctr->fetch_closest[i] = closest_threads; ctr->fetch_any[i] = any_threads; }
 }
 
 static hipEvent_t next_event(rtx_ctx * c) {
@@ -374,12 +385,12 @@ static hipEvent_t next_event(rtx_ctx * c) {
 }
 
 template <typename F>
-static void launch_timed(rtx_ctx * c, const char * name, F && launch) {
+static void launch_timed(rtx_ctx * c, const char * name, hipStream_t stream, F && launch) {
     if (c->timing) {
         KernelTime kt; kt.name = name; kt.a = next_event(c); kt.b = next_event(c);
-        hipEventRecord(kt.a, c->stream);
+        hipEventRecord(kt.a, stream);                 // events on the stream the kernel is launched on
         launch();
-        hipEventRecord(kt.b, c->stream);
+        hipEventRecord(kt.b, stream);
         c->times.push_back(kt);
     } else launch();
 }
@@ -393,6 +404,7 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
     const bool count_work = (flags & RTX_RENDER_COUNT_WORK) != 0;
     const bool simple = (flags & RTX_RENDER_SIMPLE_TRACE) != 0;
     const bool cull = (flags & RTX_RENDER_CULL_DEAD_SHADOW_RAYS) != 0 && !simple && !count_work;
+    c->serial = (flags & RTX_RENDER_SERIAL) != 0;
 
     // stats of this call: reset accumulators (WorkerThread.cpp:120 zeroes them per frame)
     HIP_OK(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), c->stream));
@@ -410,26 +422,49 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
         DevQueues q = c->q;
         q.first_tile = first_tile + done * tile_stride; q.tile_stride = tile_stride; q.tile_count = n; q.primary_slots = n * 1024;
         const DevScene sc = c->scene;
-        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, q.counters, (uint32_t)q.primary_slots);
+        const bool plain = count_work || simple;
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, q.counters, (uint32_t)q.primary_slots,
+                           (uint32_t)((plain ? c->trace_blocks_count : c->trace_blocks_closest) * RTX_TRACE_BLOCK),
+                           (uint32_t)((plain ? c->trace_blocks_count : c->trace_blocks_any) * RTX_TRACE_BLOCK));
+        // Main stream: closest(d) -> shade(d) for d = 0..D.  Shadow rays depend only on shade, so in the default (fast)
+        // configuration they run on a second stream: any(level 0) starts after shade(0) and overlaps the deeper levels'
+        // closest/shade kernels; the shadow rays of levels 1..D are traced by ONE more launch after shade(D).  This removes
+        // three of the per-launch tails (a persistent trace launch has a ~0.17 ms floor set by its slowest rays).
+        const bool overlap = !count_work && !simple && sc.light_count > 0 && !c->serial;
         for (int level = 0; level < levels; level++) {
-            launch_timed(c, "k_trace_closest", [&] {
+            launch_timed(c, "k_trace_closest", c->stream, [&] {
                 if (count_work)   hipLaunchKernelGGL((k_trace<false, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (simple)  hipLaunchKernelGGL((k_trace<false, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else              hipLaunchKernelGGL((k_trace_fast<false>),   dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else              hipLaunchKernelGGL((k_trace_fast<false>),   dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
             });
-            launch_timed(c, "k_shade", [&] {
+            launch_timed(c, "k_shade", c->stream, [&] {
                 if (count_work) hipLaunchKernelGGL((k_shade<true, false>),  dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
                 else if (cull)  hipLaunchKernelGGL((k_shade<false, true>),  dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
                 else            hipLaunchKernelGGL((k_shade<false, false>), dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
             });
-            if (sc.light_count > 0) launch_timed(c, "k_trace_any", [&] {
+            if (sc.light_count == 0) continue;
+            if (overlap) {
+                if (level == 0) {
+                    hipEventRecord(c->ev_shade0, c->stream);
+                    hipStreamWaitEvent(c->any_stream, c->ev_shade0, 0);
+                    launch_timed(c, "k_trace_any", c->any_stream, [&] {
+                        hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 0, 0); });
+                }
+                if (level == levels - 1 && levels > 1) {
+                    hipEventRecord(c->ev_shade_last, c->stream);
+                    hipStreamWaitEvent(c->any_stream, c->ev_shade_last, 0);
+                    launch_timed(c, "k_trace_any", c->any_stream, [&] {
+                        hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 1, levels - 1); });
+                }
+            } else launch_timed(c, "k_trace_any", c->stream, [&] {
                 if (count_work)   hipLaunchKernelGGL((k_trace<true, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (simple)  hipLaunchKernelGGL((k_trace<true, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else              hipLaunchKernelGGL((k_trace_fast<true>),   dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else              hipLaunchKernelGGL((k_trace_fast<true>),   dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
             });
         }
+        if (overlap) { hipEventRecord(c->ev_any_done, c->any_stream); hipStreamWaitEvent(c->stream, c->ev_any_done, 0); }
         for (int level = levels - 1; level >= 0; level--)
-            launch_timed(c, "k_resolve", [&] { hipLaunchKernelGGL(k_resolve, dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level); });
+            launch_timed(c, "k_resolve", c->stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level); });
     }
     HIP_OK(c, hipGetLastError());
     c->stats_pending = true;

@@ -150,18 +150,27 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
         return (sp < RTX_LDS_STACK) ? stk[sp * RTX_WAVE] : spill[(sp - RTX_LDS_STACK) * spill_stride];
     };
 
-    bool exhausted = false;
+    bool exhausted = false, first_round = true;
     for (;;) {
         // ---------------- refill idle lanes from the queue (ballot + prefix rank) ----------------
         const unsigned long long idle = __ballot(!has_ray);
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= RTX_REFILL_MIN) {
-            const int leader = __ffsll((long long)idle) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(head, (uint32_t)n_idle);
-            base = __shfl(base, leader);
-            if (base + (uint32_t)n_idle >= total) exhausted = true;
-            const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            uint32_t idx;
+            if (first_round) {
+                // round one is a static assignment (thread i takes ray i): the queue head was initialised to the grid size
+                // by k_begin_batch, so a launch with fewer rays than resident lanes performs no atomic at all
+                first_round = false;
+                idx = (uint32_t)gtid;
+                if ((uint32_t)(gridDim.x * blockDim.x) >= total) exhausted = true;
+            } else {
+                const int leader = __ffsll((long long)idle) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(head, (uint32_t)n_idle);
+                base = __shfl(base, leader);
+                if (base + (uint32_t)n_idle >= total) exhausted = true;
+                idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            }
             if (!has_ray && idx < total) {
                 bool live = true;
                 if (ANY) {
@@ -327,7 +336,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
 // Work counters are produced by k_trace<ANY, true> (reference-order accounting); this kernel has none.
 template <bool ANY>
 __global__ __launch_bounds__(RTX_TRACE_BLOCK, ANY ? RTX_WAVES_ANY : RTX_WAVES_CLOSEST)
-void k_trace_fast(const DevScene sc, const DevQueues q, const int level) {
+void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const int level_hi) {
     __shared__ int lds_stack[RTX_TRACE_BLOCK / RTX_WAVE][RTX_LDS_STACK][RTX_WAVE];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -337,10 +346,11 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level) {
     const int spill_stride = q.spill_threads;
 
     DevCounters * const ctr = q.counters;
-    const uint32_t lit_n = ctr->lit_count[level];
-    const uint32_t total = ANY ? lit_n * (uint32_t)sc.light_count : ctr->ray_count[level];
+    // shadow rays: one launch may cover the levels [level, level_hi]; closest-hit rays: exactly one level
+    uint32_t total = 0;
+    if (ANY) { for (int d = level; d <= level_hi; d++) total += ctr->lit_count[d] * (uint32_t)sc.light_count; }
+    else total = ctr->ray_count[level];
     uint32_t * const head = ANY ? &ctr->fetch_any[level] : &ctr->fetch_closest[level];
-    const int lit_cap = q.level_cap[level];
     const bool ordered = sc.traversal_strategy == RTX_TRAVERSE_ORDERED;
 
     bool has_ray = false, have_cur = false;
@@ -370,22 +380,35 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level) {
         has_ray = false; have_cur = false;
     };
 
-    bool exhausted = false;
+    bool exhausted = false, first_round = true;
     for (;;) {
         const unsigned long long idle = __ballot(!has_ray);
         const int n_idle = __popcll(idle);
         if (!exhausted && n_idle >= RTX_REFILL_MIN) {
-            const int leader = __ffsll((long long)idle) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(head, (uint32_t)n_idle);
-            base = __shfl(base, leader);
-            if (base + (uint32_t)n_idle >= total) exhausted = true;
-            const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            uint32_t idx;
+            if (first_round) {
+                // round one is a static assignment (thread i takes ray i): the queue head was initialised to the grid size
+                // by k_begin_batch, so a launch with fewer rays than resident lanes performs no atomic at all
+                first_round = false;
+                idx = (uint32_t)gtid;
+                if ((uint32_t)(gridDim.x * blockDim.x) >= total) exhausted = true;
+            } else {
+                const int leader = __ffsll((long long)idle) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(head, (uint32_t)n_idle);
+                base = __shfl(base, leader);
+                if (base + (uint32_t)n_idle >= total) exhausted = true;
+                idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            }
             if (!has_ray && idx < total) {
                 bool live = true;
                 if (ANY) {
-                    const uint32_t light = idx / lit_n, rank = idx - light * lit_n;
-                    out_slot = (uint32_t)q.shadow_base[level] + light * (uint32_t)lit_cap + rank;
+                    // idx -> (level, light, rank): levels are concatenated, light-major inside a level
+                    uint32_t local = idx; int d = level;
+                    uint32_t lit_n = ctr->lit_count[d];
+                    while (d < level_hi && local >= lit_n * (uint32_t)sc.light_count) { local -= lit_n * (uint32_t)sc.light_count; d++; lit_n = ctr->lit_count[d]; }
+                    const uint32_t light = local / lit_n, rank = local - light * lit_n;
+                    out_slot = (uint32_t)q.shadow_base[d] + light * (uint32_t)q.level_cap[d] + rank;
                     const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot];
                     wo = V3(s0.x, s0.y, s0.z); tcur = s0.w; wd = V3(s1.x, s1.y, s1.z);
                     if (tcur < 0.0f) live = false;        // culled by k_shade<.., CULL>: contribution is exactly zero, already resolved

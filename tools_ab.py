@@ -4,11 +4,14 @@ import json, os, subprocess, sys
 variants = sys.argv[1:]
 for v in variants:
     env = dict(os.environ)
+    extra = []
+    if ":" in v:
+        v, flag = v.split(":", 1); extra = ["--" + flag]
     if v != "base":
         env["RTX_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpu-raytracer_amd", "csrc", f"librtx_hip_{v}.so")
-    out = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "3", "--cpu-seconds", "0"], capture_output=True, text=True, env=env)
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "3", "--cpu-seconds", "0"] + extra, capture_output=True, text=True, env=env)
     try:
         j = json.loads(out.stdout.strip().splitlines()[-1])
-        print(v, j["ms_per_step"], j["value"], {k: round(x["total_ms_per_step"], 3) for k, x in j["kernels"].items()}, flush=True)
+        print(v, extra, j["ms_per_step"], j["value"], {k: round(x["total_ms_per_step"], 3) for k, x in j["kernels"].items()}, flush=True)
     except Exception as e:
         print(v, "FAILED", out.stderr[-400:], flush=True)
