@@ -60,11 +60,12 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--simple-trace", action="store_true", help="A/B: plain pop-and-test traversal kernels")
-    ap.add_argument("--frames-in-flight", type=int, default=2, help="contexts rendering consecutive frames concurrently (1 = one frame at a time)")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="contexts rendering consecutive frames concurrently (1 = one frame at a time)")
     ap.add_argument("--simulate-ranks", type=int, default=0, help="single-GPU rehearsal: render only the tile shard rank 0 of N would own (no gather)")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL gather plumbing even with one rank (single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra passes (serial-mode timings, culling figure): use under rocprofv3 so its per-kernel averages cover only the benchmark's own launches")
-    ap.add_argument("--serial", action="store_true", help="RTX_RENDER_SERIAL for the timed loop (no overlap of shadow-ray kernels)")
+    ap.add_argument("--serial", action="store_true", help="RTX_RENDER_SERIAL for the timed loop (one stream per frame); default when more than one frame is in flight")
+    ap.add_argument("--overlap", action="store_true", help="force the two-stream intra-frame overlap even with several frames in flight")
     ap.add_argument("--cull", action="store_true", help="time with RTX_RENDER_CULL_DEAD_SHADOW_RAYS as the main figure (default: reported as an extra)")
     args = ap.parse_args()
 
@@ -109,6 +110,8 @@ def main():
     # (own queues, framebuffer and streams each), so one frame's kernel tails overlap the next frame's start.  Every frame
     # is rendered and gathered completely; --frames-in-flight 1 gives the one-frame-at-a-time latency figure.
     nfl = max(1, args.frames_in_flight)
+    # measured on MI355X (ms per cfg3 frame, overlap / serial): 1 frame in flight 3.70 / 4.02, 2: 3.26 / 3.13, 3: 3.61 / 2.81, 4: 3.64 / 3.06
+    serial = args.serial or (nfl > 1 and not args.overlap)
 
     class Slot:
         pass
@@ -129,7 +132,7 @@ def main():
     def step():
         sl = slots[frame_no[0] % nfl]
         frame_no[0] += 1
-        sl.r.render_async(first, stride, count, simple_trace=args.simple_trace, cull_dead_shadow_rays=args.cull, serial=args.serial)
+        sl.r.render_async(first, stride, count, simple_trace=args.simple_trace, cull_dead_shadow_rays=args.cull, serial=serial)
         if sl.gather is not None:
             with torch.cuda.stream(sl.stream):
                 sl.gather(sl.fb_packed)
@@ -163,18 +166,26 @@ def main():
     for sl in slots:
         ktimes += sl.r.kernel_times()
         sl.r.enable_timing(False)
-    # extra (not the headline): the same frame with dead shadow rays counted but not traversed
-    t_cull = None
+    # extras (not the headline): (a) the same pipeline with dead shadow rays counted but not traversed; (b) one frame at a time
+    t_cull = t_single = None
     if world == 1 and not args.cull and not args.simple_trace and gather is None and not args.no_extras:
-        for _ in range(2):
-            r.render_async(first, stride, count, cull_dead_shadow_rays=True)
-        sync()
-        tc0 = time.perf_counter()
-        for _ in range(args.steps):
-            r.render_async(first, stride, count, cull_dead_shadow_rays=True)
-        sync()
-        t_cull = 1000.0 * (time.perf_counter() - tc0) / max(args.steps, 1)
-        r.render_async(first, stride, count)          # leave the un-culled frame in the framebuffer for the parity check
+        def timed(fn, n):
+            for _ in range(3):
+                fn()
+            sync()
+            a = time.perf_counter()
+            for _ in range(n):
+                fn()
+            sync()
+            return 1000.0 * (time.perf_counter() - a) / n
+
+        def step_cull():
+            sl = slots[frame_no[0] % nfl]; frame_no[0] += 1
+            sl.r.render_async(first, stride, count, cull_dead_shadow_rays=True, serial=serial)
+        t_cull = timed(step_cull, args.steps)
+        t_single = timed(lambda: r.render_async(first, stride, count), min(args.steps, 15))    # slot 0 only, intra-frame overlap
+        for sl in slots:                                # leave un-culled frames in the framebuffers for the parity check
+            sl.r.render_async(first, stride, count)
         sync()
     # extra: per-kernel durations with every kernel on one stream (no overlap between shadow-ray and closest-hit kernels)
     serial_times = None
@@ -233,13 +244,14 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "width": W, "height": H, "bounces": int(sc.config["bounces"][0]),
                        "triangles": sc.triangle_refs(), "bvh_nodes": int(sum(len(b.nodes) for b in sc.blas)),
-                       "frames_in_flight": nfl, "tiles": T, "sharding": "tile t -> GPU t mod N; RCCL gather of packed tiles to rank 0" if world > 1 else "single GPU"},
+                       "frames_in_flight": nfl, "streams_per_frame": 1 if serial else 2, "tiles": T, "sharding": "tile t -> GPU t mod N; RCCL gather of packed tiles to rank 0" if world > 1 else "single GPU"},
             "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3], "total": tot[4]},
             "mprimary_per_s": round(tot[0] / (ms_per_step * 1e-3) * 1e-6, 3),
             "kernels": kern,
             "gathered_frame_equals_single_gpu_frame": gather_ok,
             "kernels_serial_mode": None if not serial_times else {k: {"launches_per_frame": len(v) / min(args.steps, 10), "avg_ms": round(float(np.mean(v)), 5), "total_ms_per_frame": round(float(np.sum(v)) / min(args.steps, 10), 4)}
                                                                     for k, v in _group(serial_times).items()},
+            "latency_ms_one_frame_at_a_time": None if t_single is None else round(t_single, 4),
             "extra_cull_dead_shadow_rays": None if t_cull is None else {"ms_per_step": round(t_cull, 4), "note": "RTX_RENDER_CULL_DEAD_SHADOW_RAYS: identical frame and ray counts; shadow rays with an exactly-zero light contribution are counted but not traversed"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": None if achieved is None else round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / 8000.0, 5), "traffic": traffic,

@@ -23,6 +23,12 @@
 #ifndef RTX_TRACE_STEPS
 #define RTX_TRACE_STEPS  32     // traversal steps between refill checks
 #endif
+#ifndef RTX_INNER_REPEAT
+#define RTX_INNER_REPEAT 1      // inner-node steps per traversal iteration (while-while style convergence)
+#endif
+#ifndef RTX_INNER_MIN_LANES
+#define RTX_INNER_MIN_LANES 32  // keep repeating the inner step while at least this many lanes want it
+#endif
 #ifndef RTX_WAVES_ANY
 #define RTX_WAVES_ANY     1     // __launch_bounds__ min waves per SIMD for the shadow-ray kernel
 #endif
@@ -465,6 +471,11 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
 
         for (int it = 0; it < RTX_TRACE_STEPS; it++) {
             // ---- A: inner node: fetch the child pair, test both, descend into the near one ----
+            // (repeated while most lanes are still walking inner nodes: lanes that reached a leaf or ran dry wait a little,
+            //  which keeps the wave converged on the dominant step)
+            #pragma unroll 1
+            for (int rep = 0; rep < RTX_INNER_REPEAT; rep++) {
+            if (rep > 0 && __popcll(__ballot(has_ray && have_cur && (cur_cnt & 0x3fffffff) == 0)) < RTX_INNER_MIN_LANES) break;
             if (has_ray && have_cur && (cur_cnt & 0x3fffffff) == 0) {
                 const int left = cur_first;
                 const float4 la = cur_nodes[2 * left], lb = cur_nodes[2 * left + 1], ra = cur_nodes[2 * left + 2], rb = cur_nodes[2 * left + 3];
@@ -493,6 +504,7 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
                 } else if (p_far) {
                     cur_first = far_first; cur_cnt = far_cnt;
                 } else have_cur = false;
+            }
             }
             // ---- B: leaf ----
             if (has_ray && have_cur && (cur_cnt & 0x3fffffff) > 0) {
