@@ -18,7 +18,7 @@
 
 #define RTX_SHADE_BLOCK 256
 #ifndef RTX_WAVES_SHADE
-#define RTX_WAVES_SHADE 1     // __launch_bounds__ min waves per SIMD for k_shade
+#define RTX_WAVES_SHADE 3     // __launch_bounds__ min waves per SIMD for k_shade (168 VGPRs: the kernel needs 169 unconstrained)
 #endif
 
 struct HitFull {          // RayHit, RayHit.h:4-36
@@ -159,7 +159,9 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
     const int bounces_left = sc.bounces - level;
     const int nL = sc.light_count;
     const int lit_cap = q.level_cap[level];
-    uint32_t n_shadow = 0, n_refl = 0, n_refr = 0, n_primary = 0, n_shaded = 0, n_sky = 0, n_texels = 0, n_trihit = 0;
+    // wave-uniform tallies (SGPRs): ballot popcounts instead of one VGPR counter per statistic
+    uint32_t n_shadow = 0, n_refl = 0, n_refr = 0, n_primary = 0, n_shaded = 0, n_sky = 0, n_trihit = 0;
+    uint32_t n_texels = 0;      // per lane, COUNT builds only
 
     for (uint32_t base = wave_global * 64u; base < count; base += n_waves * 64u) {
         const uint32_t idx = base + lane;
@@ -177,7 +179,6 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
                 primary_pixel(sc, q, idx, px, py);
                 primary_ray(sc, px, py, ray, true);
                 pixel = py * sc.width + px;
-                n_primary++;
             } else {
                 const float4 r0 = q.r0[slot], r1 = q.r1[slot], r2 = q.r2[slot], r3 = q.r3[slot], r4 = q.r4[slot];
                 ray.o = V3(r0.x, r0.y, r0.z); ray.d = V3(r0.w, r1.x, r1.y);
@@ -186,6 +187,7 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
                 pixel = as_i(r4.z); parent = as_i(r4.w);
             }
         }
+        if (level == 0) n_primary += (uint32_t)__popcll(__ballot(valid));
         const int prim = as_i(h0.w);
         const float t = h0.x;
         const bool is_hit = valid && PRIM_KIND(prim) != PRIM_NONE;
@@ -199,29 +201,32 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
 
         if (valid && !is_hit) {                                       // Raytracer.cpp:105-111
             albedo = sky_sample(sc.sky, sc.sky_size, ray.d);
-            n_sky++;
         }
         if (is_hit) {
             flags = NF_HIT;
             const int kind = PRIM_KIND(prim), pi = PRIM_INDEX(prim);
-            if (kind == PRIM_TRI) { rebuild_triangle_hit(sc, pi, tri, t, h0.y, h0.z, ray, h); n_trihit++; }
+            if (kind == PRIM_TRI) rebuild_triangle_hit(sc, pi, tri, t, h0.y, h0.z, ray, h);
             else if (kind == PRIM_SPHERE) rebuild_sphere_hit(sc, sc.spheres[pi], t, ray, h);
             else rebuild_plane_hit(sc, sc.planes[pi], t, ray, h);
 
             const rtx_material & m = sc.materials[h.material_id];     // Material::get_albedo, Material.h:16-22
-            n_shaded++;
             albedo = v3p(m.diffuse);
             if (m.texture_id >= 0) {
                 TexCtx tc; tc.t = &sc.textures[m.texture_id]; tc.fetches = 0;
                 const bool de = sc.diff_enabled != 0;
                 const v3 tex = texture_sample(tc, sc, h.u, h.v, de ? h.ds_dx : 0.0f, de ? h.ds_dy : 0.0f, de ? h.dt_dx : 0.0f, de ? h.dt_dy : 0.0f);
                 albedo = vmul(albedo, tex);
-                n_texels += tc.fetches;
+                if (COUNT) n_texels += tc.fetches;
             }
             Ks = v3p(m.reflection); Kt = v3p(m.transmittance); ior = m.index_of_refraction;
             if (vdot(albedo, albedo) > 0.0f) flags |= NF_LIT;         // Raytracer.cpp:143-145
         }
 
+        if (COUNT) {
+            n_sky += (uint32_t)__popcll(__ballot(valid && !is_hit));
+            n_shaded += (uint32_t)__popcll(__ballot(is_hit));
+            n_trihit += (uint32_t)__popcll(__ballot(is_hit && PRIM_KIND(prim) == PRIM_TRI));
+        }
         // ---- shadow rays: rank allocation for lit hits (ballot + popcount prefix + one atomic) ----
         const bool lit = (flags & NF_LIT) != 0;
         int lit_rank = -1;
@@ -283,19 +288,38 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
                 q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
                 if (dead) q.socc[s] = 1u;
             }
-            n_shadow += (uint32_t)nL;                                             // counted before the occlusion test (:163,180,192)
         }
+        n_shadow += (uint32_t)nL * (uint32_t)__popcll(__ballot(lit));           // counted before the occlusion test (:163,180,192)
 
         // ---- secondary rays (Raytracer.cpp:204-346) ----
-        bool spawn_refl = false, spawn_refr = false;
-        RayFull rr, rf;
+        // Each kind is computed, wave-compacted (ballot + popcount prefix + one atomicAdd per wave) and written before the
+        // next one is started, so only one child ray is live at a time (register pressure).
         float F_r = 0.0f;
         v3 absorption = V3(0, 0, 0);
-        if (is_hit && bounces_left > 0) {
-            const bool reflection_mask = vdot(Ks, Ks) > 0.0f;
-            const bool refraction_mask = vdot(Kt, Kt) > 0.0f;
+        const bool deeper = is_hit && bounces_left > 0;
+        auto append_child = [&](bool spawn, const RayFull & cr, uint32_t parent_bits) {
+            const unsigned long long m = __ballot(spawn);
+            if (m == 0ull) return;
+            uint32_t b = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) b = atomicAdd(&ctr->ray_count[level + 1], (uint32_t)__popcll(m));
+            b = __shfl(b, leader);
+            if (!spawn) return;
+            const uint32_t ci = b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (ci >= (uint32_t)q.level_cap[level + 1]) { atomicOr(&ctr->error_flags, ERR_QUEUE_OVERFLOW); return; }
+            const uint32_t cs = (uint32_t)q.level_base[level + 1] + ci;
+            q.r0[cs] = make_float4(cr.o.x, cr.o.y, cr.o.z, cr.d.x);
+            q.r1[cs] = make_float4(cr.d.y, cr.d.z, cr.dO_dx.x, cr.dO_dx.y);
+            q.r2[cs] = make_float4(cr.dO_dx.z, cr.dO_dy.x, cr.dO_dy.y, cr.dO_dy.z);
+            q.r3[cs] = make_float4(cr.dD_dx.x, cr.dD_dx.y, cr.dD_dx.z, cr.dD_dy.x);
+            q.r4[cs] = make_float4(cr.dD_dy.y, cr.dD_dy.z, as_f(pixel), as_f((int)parent_bits));
+        };
+        {
+            const bool reflection_mask = deeper && vdot(Ks, Ks) > 0.0f;
+            RayFull rr;
+            rr.o = rr.d = rr.dO_dx = rr.dO_dy = rr.dD_dx = rr.dD_dy = V3(0, 0, 0);
             if (reflection_mask) {
-                flags |= NF_REFL; spawn_refl = true;
+                flags |= NF_REFL;
                 rr.o = h.point;
                 const float dn = vdot(ray.d, h.normal);
                 rr.d = vsub(ray.d, vmuls(h.normal, 2.0f * dn));                   // Math::reflect, Math.h:28-30
@@ -305,6 +329,14 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
                 rr.dD_dx = vsub(ray.dD_dx, vmuls(vadd(vmuls(h.dN_dx, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dx)), 2.0f));
                 rr.dD_dy = vsub(ray.dD_dy, vmuls(vadd(vmuls(h.dN_dy, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dy)), 2.0f));
             }
+            n_refl += (uint32_t)__popcll(__ballot(reflection_mask));
+            append_child(reflection_mask, rr, slot);
+        }
+        {
+            const bool refraction_mask = deeper && vdot(Kt, Kt) > 0.0f;
+            bool spawn_refr = false;
+            RayFull rf;
+            rf.o = rf.d = rf.dO_dx = rf.dO_dy = rf.dD_dx = rf.dD_dy = V3(0, 0, 0);
             if (refraction_mask) {
                 flags |= NF_REFR;
                 const float dot = vdot(ray.d, h.normal);
@@ -340,41 +372,8 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
                     F_r = r_0 + ((1.0f - r_0) * omc2) * (omc2 * omc);
                 }
             }
-        }
-        {
-            const unsigned long long m_a = __ballot(spawn_refl), m_b = __ballot(spawn_refr);
-            if (m_a | m_b) {
-                const int na = __popcll(m_a), nb = __popcll(m_b);
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(&ctr->ray_count[level + 1], (uint32_t)(na + nb));
-                b = __shfl(b, 0);
-                const uint32_t cap = (uint32_t)q.level_cap[level + 1];
-                const unsigned long long below = (1ull << lane) - 1ull;
-                if (spawn_refl) {
-                    const uint32_t ci = b + (uint32_t)__popcll(m_a & below);
-                    if (ci < cap) {
-                        const uint32_t cs = (uint32_t)q.level_base[level + 1] + ci;
-                        q.r0[cs] = make_float4(rr.o.x, rr.o.y, rr.o.z, rr.d.x);
-                        q.r1[cs] = make_float4(rr.d.y, rr.d.z, rr.dO_dx.x, rr.dO_dx.y);
-                        q.r2[cs] = make_float4(rr.dO_dx.z, rr.dO_dy.x, rr.dO_dy.y, rr.dO_dy.z);
-                        q.r3[cs] = make_float4(rr.dD_dx.x, rr.dD_dx.y, rr.dD_dx.z, rr.dD_dy.x);
-                        q.r4[cs] = make_float4(rr.dD_dy.y, rr.dD_dy.z, as_f(pixel), as_f((int)slot));
-                    } else atomicOr(&ctr->error_flags, ERR_QUEUE_OVERFLOW);
-                    n_refl++;
-                }
-                if (spawn_refr) {
-                    const uint32_t ci = b + (uint32_t)na + (uint32_t)__popcll(m_b & below);
-                    if (ci < cap) {
-                        const uint32_t cs = (uint32_t)q.level_base[level + 1] + ci;
-                        q.r0[cs] = make_float4(rf.o.x, rf.o.y, rf.o.z, rf.d.x);
-                        q.r1[cs] = make_float4(rf.d.y, rf.d.z, rf.dO_dx.x, rf.dO_dx.y);
-                        q.r2[cs] = make_float4(rf.dO_dx.z, rf.dO_dy.x, rf.dO_dy.y, rf.dO_dy.z);
-                        q.r3[cs] = make_float4(rf.dD_dx.x, rf.dD_dx.y, rf.dD_dx.z, rf.dD_dy.x);
-                        q.r4[cs] = make_float4(rf.dD_dy.y, rf.dD_dy.z, as_f(pixel), as_f((int)(slot | 0x80000000u)));
-                    } else atomicOr(&ctr->error_flags, ERR_QUEUE_OVERFLOW);
-                    n_refr++;
-                }
-            }
+            n_refr += (uint32_t)__popcll(__ballot(spawn_refr));
+            append_child(spawn_refr, rf, slot | 0x80000000u);
         }
 
         if (valid) {
@@ -387,15 +386,8 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
         }
     }
 
-    // statistics: wave reduce, one atomic per counter per wave
-    for (int off = 32; off > 0; off >>= 1) {
-        n_shadow += __shfl_down(n_shadow, off); n_refl += __shfl_down(n_refl, off); n_refr += __shfl_down(n_refr, off);
-        n_primary += __shfl_down(n_primary, off);
-        if (COUNT) {
-            n_shaded += __shfl_down(n_shaded, off); n_sky += __shfl_down(n_sky, off);
-            n_texels += __shfl_down(n_texels, off); n_trihit += __shfl_down(n_trihit, off);
-        }
-    }
+    // statistics: the tallies are already per-wave sums; one atomic per counter per wave
+    if (COUNT) for (int off = 32; off > 0; off >>= 1) n_texels += __shfl_down(n_texels, off);
     if (lane == 0) {
         if (n_primary) atomicAdd(&ctr->stats[0], (unsigned long long)n_primary);
         if (n_shadow)  atomicAdd(&ctr->stats[1], (unsigned long long)n_shadow);

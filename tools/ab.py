@@ -8,8 +8,8 @@ for v in variants:
     if ":" in v:
         v, flag = v.split(":", 1); extra = ["--" + flag]
     if v != "base":
-        env["RTX_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpu-raytracer_amd", "csrc", f"librtx_hip_{v}.so")
-    out = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "3", "--cpu-seconds", "0"] + extra, capture_output=True, text=True, env=env)
+        env["RTX_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cpu-raytracer_amd", "csrc", f"librtx_hip_{v}.so")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py"), "--steps", "20", "--warmup", "3", "--cpu-seconds", "0"] + extra, capture_output=True, text=True, env=env)
     try:
         j = json.loads(out.stdout.strip().splitlines()[-1])
         print(v, extra, j["ms_per_step"], j["value"], {k: round(x["total_ms_per_step"], 3) for k, x in j["kernels"].items()}, flush=True)
