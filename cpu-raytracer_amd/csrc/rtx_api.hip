@@ -415,7 +415,8 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
     int rc = alloc_queues(c, batch_tiles);
     if (rc) return rc;
     const int levels = c->cfg.bounces + 1;
-    const int stream_blocks = c->n_cu * 8;
+    const int stream_blocks = c->n_cu * 8;          // k_resolve (256 threads)
+    const int shade_blocks = c->n_cu * 4;           // k_shade (RTX_SHADE_BLOCK = 384 threads, 2 resident blocks per CU)
 
     for (int done = 0; done < tile_count; done += batch_tiles) {
         const int n = (tile_count - done) < batch_tiles ? (tile_count - done) : batch_tiles;
@@ -438,9 +439,9 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
                 else              hipLaunchKernelGGL((k_trace_fast<false>),   dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
             });
             launch_timed(c, "k_shade", c->stream, [&] {
-                if (count_work) hipLaunchKernelGGL((k_shade<true, false>),  dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
-                else if (cull)  hipLaunchKernelGGL((k_shade<false, true>),  dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
-                else            hipLaunchKernelGGL((k_shade<false, false>), dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
+                if (count_work) hipLaunchKernelGGL((k_shade<true, false>),  dim3(shade_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
+                else if (cull)  hipLaunchKernelGGL((k_shade<false, true>),  dim3(shade_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
+                else            hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
             });
             if (sc.light_count == 0) continue;
             if (overlap) {
@@ -464,7 +465,7 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
         }
         if (overlap) { hipEventRecord(c->ev_any_done, c->any_stream); hipStreamWaitEvent(c->stream, c->ev_any_done, 0); }
         for (int level = levels - 1; level >= 0; level--)
-            launch_timed(c, "k_resolve", c->stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(stream_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level); });
+            launch_timed(c, "k_resolve", c->stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(stream_blocks), dim3(256), 0, c->stream, sc, q, level); });
     }
     HIP_OK(c, hipGetLastError());
     c->stats_pending = true;

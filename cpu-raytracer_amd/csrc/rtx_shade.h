@@ -16,7 +16,9 @@
 #include "rtx_texture.h"
 #include "rtx_trace.h"
 
-#define RTX_SHADE_BLOCK 256
+#ifndef RTX_SHADE_BLOCK
+#define RTX_SHADE_BLOCK 384     // 6 waves aggregate their queue appends into ONE global atomic; 2 blocks/CU = 3 waves/SIMD at 168 VGPRs
+#endif
 #ifndef RTX_WAVES_SHADE
 #define RTX_WAVES_SHADE 3     // __launch_bounds__ min waves per SIMD for k_shade (168 VGPRs: the kernel needs 169 unconstrained)
 #endif
@@ -154,17 +156,37 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
     DevCounters * const ctr = q.counters;
     const uint32_t count = ctr->ray_count[level];
     const int lane = threadIdx.x & 63;
-    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const int bounces_left = sc.bounces - level;
     const int nL = sc.light_count;
+    // Block-level compaction: every wave publishes its popcount in LDS, one thread performs the global atomicAdd for the
+    // whole workgroup, each lane's slot = block base + counts of the lower waves + its popcount-prefix rank.  (One atomic
+    // per WAVE kept k_shade at the ~90 atomics/us a single counter sustains: 32 k waves x 3 counters at level 0.)
+    __shared__ uint32_t s_wave_cnt[RTX_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_block_base;
+    const int wave_in_block = threadIdx.x >> 6;
+    auto block_alloc = [&](bool want, uint32_t * counter) -> uint32_t {
+        const unsigned long long m = __ballot(want);
+        if (lane == 0) s_wave_cnt[wave_in_block] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < RTX_SHADE_BLOCK / 64; w++) tot += s_wave_cnt[w];
+            s_block_base = tot ? atomicAdd(counter, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t off = s_block_base;
+        for (int w = 0; w < wave_in_block; w++) off += s_wave_cnt[w];
+        const uint32_t r = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        __syncthreads();                          // s_wave_cnt / s_block_base are reused by the next allocation
+        return r;
+    };
     const int lit_cap = q.level_cap[level];
     // wave-uniform tallies (SGPRs): ballot popcounts instead of one VGPR counter per statistic
     uint32_t n_shadow = 0, n_refl = 0, n_refr = 0, n_primary = 0, n_shaded = 0, n_sky = 0, n_trihit = 0;
     uint32_t n_texels = 0;      // per lane, COUNT builds only
 
-    for (uint32_t base = wave_global * 64u; base < count; base += n_waves * 64u) {
-        const uint32_t idx = base + lane;
+    for (uint32_t bbase = blockIdx.x * RTX_SHADE_BLOCK; bbase < count; bbase += gridDim.x * RTX_SHADE_BLOCK) {   // block-uniform trip count
+        const uint32_t idx = bbase + threadIdx.x;
         bool valid = idx < count;
         const uint32_t slot = (uint32_t)q.level_base[level] + (valid ? idx : 0u);
 
@@ -231,14 +253,8 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
         const bool lit = (flags & NF_LIT) != 0;
         int lit_rank = -1;
         {
-            const unsigned long long m_lit = __ballot(lit);
-            if (m_lit) {
-                const int leader = __ffsll((long long)m_lit) - 1;
-                uint32_t b = 0;
-                if (lane == leader) b = atomicAdd(&ctr->lit_count[level], (uint32_t)__popcll(m_lit));
-                b = __shfl(b, leader);
-                if (lit) lit_rank = (int)(b + (uint32_t)__popcll(m_lit & ((1ull << lane) - 1ull)));
-            }
+            const uint32_t rnk = block_alloc(lit, &ctr->lit_count[level]);
+            if (lit) lit_rank = (int)rnk;
         }
         if (lit) {
             const v3 to_camera = vnormalize(vsub(v3p(sc.cam_pos), h.point));     // Raytracer.cpp:152 (camera, not ray origin)
@@ -298,14 +314,8 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
         v3 absorption = V3(0, 0, 0);
         const bool deeper = is_hit && bounces_left > 0;
         auto append_child = [&](bool spawn, const RayFull & cr, uint32_t parent_bits) {
-            const unsigned long long m = __ballot(spawn);
-            if (m == 0ull) return;
-            uint32_t b = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if (lane == leader) b = atomicAdd(&ctr->ray_count[level + 1], (uint32_t)__popcll(m));
-            b = __shfl(b, leader);
+            const uint32_t ci = block_alloc(spawn, &ctr->ray_count[level + 1]);
             if (!spawn) return;
-            const uint32_t ci = b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (ci >= (uint32_t)q.level_cap[level + 1]) { atomicOr(&ctr->error_flags, ERR_QUEUE_OVERFLOW); return; }
             const uint32_t cs = (uint32_t)q.level_base[level + 1] + ci;
             q.r0[cs] = make_float4(cr.o.x, cr.o.y, cr.o.z, cr.d.x);
@@ -413,7 +423,7 @@ RTX_D uint32_t plot_pack(v3 c) {
     return (uint32_t)((r << 16) | (g << 8) | b);
 }
 
-__global__ __launch_bounds__(RTX_SHADE_BLOCK)
+__global__ __launch_bounds__(256)
 void k_resolve(const DevScene sc, const DevQueues q, const int level) {
     const DevCounters * const ctr = q.counters;
     uint32_t count = ctr->ray_count[level];
