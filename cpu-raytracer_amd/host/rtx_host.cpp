@@ -176,7 +176,7 @@ struct rtxh_tlas {
 };
 
 namespace {
-struct TlasBuild {
+struct TlasBuild {        // BVHBuilders::build_bvh<PrimitiveType>: used for Mesh instances (TLAS) and for triangles (reference BLAS)
     const float * pos; const float * aabb; rtxh_tlas * t; rtx_bvh_node * nodes; int node_index;
     Box prim_box(int i) const { Box b; b.mn = mk(aabb[6 * i], aabb[6 * i + 1], aabb[6 * i + 2]); b.mx = mk(aabb[6 * i + 3], aabb[6 * i + 4], aabb[6 * i + 5]); return b; }
     float p(int i, int d) const { return pos[3 * i + d]; }
@@ -257,6 +257,29 @@ extern "C" int rtxh_tlas_build(rtxh_tlas * t, const float * positions, const flo
     memcpy(indices_out, t->idx[0].data(), sizeof(int) * n);
     *node_count_out = b.node_index;
     return RTX_OK;
+}
+
+// The reference's non-spatial BLAS build (BottomLevelBVH::build_bvh, BottomLevelBVH.cpp:72-106): the same generic builder
+// over triangles, keyed by Triangle::get_position (Triangle.h:22-24) with AABBs from Triangle::calc_aabb (:14-20).
+extern "C" int rtxh_blas_build_reference_bvh(const float * positions, int32_t n, rtx_bvh_node * nodes_out, int32_t * node_count_out, int32_t * order_out) {
+    if (!positions || n <= 0 || !nodes_out || !node_count_out || !order_out) return RTX_ERR_INVALID_ARG;
+    std::vector<float> cen(3 * (size_t)n), box(6 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        const float * p = positions + 9 * (size_t)i;
+        V a = mk(p[0], p[1], p[2]), b = mk(p[3], p[4], p[5]), c = mk(p[6], p[7], p[8]);
+        Box t = empty_box(); expand(t, a); expand(t, b); expand(t, c);
+        fix_if_needed(t); fix_if_needed(t);                                   // AABB::from_points, then calc_aabb's own call
+        V g = (a + b + c) * (1.0f / 3.0f);
+        cen[3 * (size_t)i] = g.x; cen[3 * (size_t)i + 1] = g.y; cen[3 * (size_t)i + 2] = g.z;
+        box[6 * (size_t)i] = t.mn.x; box[6 * (size_t)i + 1] = t.mn.y; box[6 * (size_t)i + 2] = t.mn.z;
+        box[6 * (size_t)i + 3] = t.mx.x; box[6 * (size_t)i + 4] = t.mx.y; box[6 * (size_t)i + 5] = t.mx.z;
+    }
+    rtxh_tlas * t = nullptr;
+    int rc = rtxh_tlas_create(n, &t);
+    if (rc) return rc;
+    rc = rtxh_tlas_build(t, cen.data(), box.data(), nodes_out, order_out, node_count_out);
+    rtxh_tlas_destroy(t);
+    return rc;
 }
 
 // =================================================================================================

@@ -19,7 +19,8 @@ from .ctypes_structs import RtxCamera, RtxTextureDesc
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "host", "librtx_host.so")
 EXPORTS = ["rtxh_camera_basis", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
-           "rtxh_tlas_build", "rtxh_blas_build", "rtxh_texture_mips", "rtxh_atrium_generate", "rtxh_mesh_free"]
+           "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_texture_mips", "rtxh_atrium_generate", "rtxh_mesh_free",
+           "rtxh_obj_load", "rtxh_obj_free"]
 
 PI = np.float32(3.14159265359)          # Util.h:8
 
@@ -29,6 +30,11 @@ class RtxhMesh(C.Structure):
                 ("material_ids", C.POINTER(C.c_int32)), ("triangle_count", C.c_int32), ("material_count", C.c_int32)]
 
 
+class RtxhObj(C.Structure):
+    _fields_ = [("mesh", RtxhMesh), ("materials", C.c_void_p), ("texture_names", C.c_void_p)]
+
+
+TEXNAME_MAX = 512
 _lib = None
 
 
@@ -47,6 +53,9 @@ def lib():
         l.rtxh_tlas_destroy.argtypes = [vp]
         l.rtxh_tlas_build.argtypes = [vp, vp, vp, vp, vp, C.POINTER(i32)]
         l.rtxh_blas_build.argtypes = [vp, i32, i32, vp, C.POINTER(i32), vp]
+        l.rtxh_blas_build_reference_bvh.argtypes = [vp, i32, vp, C.POINTER(i32), vp]
+        l.rtxh_obj_load.argtypes = [C.c_char_p, C.POINTER(RtxhObj)]
+        l.rtxh_obj_free.argtypes = [C.POINTER(RtxhObj)]
         l.rtxh_texture_mips.argtypes = [vp, i32, i32, C.POINTER(RtxTextureDesc), C.POINTER(C.c_int64)]
         l.rtxh_atrium_generate.argtypes = [C.c_uint32, i32, C.POINTER(RtxhMesh)]
         l.rtxh_mesh_free.argtypes = [C.POINTER(RtxhMesh)]
@@ -119,8 +128,27 @@ class Tlas:
             pass
 
 
+def load_obj(path: str):
+    """OBJLoader::load_obj equivalent: (positions (n,3,3), normals, texcoords (n,3,2), material ids, MATERIAL array,
+    texture path per material or None)."""
+    o = RtxhObj()
+    rc = lib().rtxh_obj_load(path.encode(), C.byref(o))
+    if rc:
+        raise RuntimeError(f"rtxh_obj_load({path}) failed: {rc}")
+    n, nm = o.mesh.triangle_count, o.mesh.material_count
+    pos = np.ctypeslib.as_array(o.mesh.positions, (n, 3, 3)).copy()
+    nrm = np.ctypeslib.as_array(o.mesh.normals, (n, 3, 3)).copy()
+    uv = np.ctypeslib.as_array(o.mesh.texcoords, (n, 3, 2)).copy()
+    mid = np.ctypeslib.as_array(o.mesh.material_ids, (n,)).copy()
+    mats = np.frombuffer((C.c_char * (nm * sio.MATERIAL.itemsize)).from_address(o.materials), sio.MATERIAL).copy()
+    names_raw = (C.c_char * (nm * TEXNAME_MAX)).from_address(o.texture_names).raw
+    names = [names_raw[i * TEXNAME_MAX:(i + 1) * TEXNAME_MAX].split(b"\0")[0].decode() or None for i in range(nm)]
+    lib().rtxh_obj_free(C.byref(o))
+    return pos, nrm, uv, mid, mats, names
+
+
 def build_blas(positions: np.ndarray, normals: np.ndarray, texcoords: np.ndarray, material_ids: np.ndarray,
-               material_offset: int, bins: int = 32) -> sio.Blas:
+               material_offset: int, bins: int = 32, reference_bvh: bool = False) -> sio.Blas:
     """Triangle soup (n,3,3) + per-vertex normals (n,3,3) + texcoords (n,3,2) -> flattened BLAS
     (TriangleHot / TriangleCold as OBJLoader.cpp:156-175 fills them)."""
     pos = _f32(positions).reshape(-1, 9)
@@ -128,7 +156,10 @@ def build_blas(positions: np.ndarray, normals: np.ndarray, texcoords: np.ndarray
     nodes = np.zeros(2 * n, sio.BVH_NODE)
     order = np.zeros(n, np.int32)
     nc = C.c_int32()
-    rc = lib().rtxh_blas_build(pos.ctypes.data, n, bins, nodes.ctypes.data, C.byref(nc), order.ctypes.data)
+    if reference_bvh:     # the reference's MESH_ACCELERATOR_BVH topology (BVHBuilders.h:8-46)
+        rc = lib().rtxh_blas_build_reference_bvh(pos.ctypes.data, n, nodes.ctypes.data, C.byref(nc), order.ctypes.data)
+    else:                 # this repo's binned-SAH builder
+        rc = lib().rtxh_blas_build(pos.ctypes.data, n, bins, nodes.ctypes.data, C.byref(nc), order.ctypes.data)
     assert rc == 0, rc
     p = pos.reshape(n, 3, 3)[order]
     nr = _f32(normals).reshape(n, 3, 3)[order]

@@ -17,6 +17,8 @@
  *                            builder (not the reference's SBVH), output in the
  *                            reference's node convention + flattened leaf order
  *                            (BVHNode.h:10-28, BottomLevelBVH.cpp:196-212)
+ *   rtxh_blas_build_reference_bvh   the reference's non-spatial BLAS builder, node for node (BVHBuilders.h:8-46)
+ *   rtxh_obj_load            OBJLoader::load_obj / load_mtl                 OBJLoader.cpp:8-187
  *   rtxh_texture_mips        Texture::load's box-filter mip chain          Texture.cpp:76-117
  *   rtxh_atrium_*            seeded procedural stand-in for the absent Sponza mesh
  */
@@ -53,6 +55,13 @@ int rtxh_tlas_build(rtxh_tlas * t, const float * positions, const float * aabbs,
 int rtxh_blas_build(const float * positions, int32_t triangle_count, int32_t bins,
                     rtx_bvh_node * nodes_out, int32_t * node_count_out, int32_t * order_out);
 
+/* The reference's NON-spatial builder (MESH_ACCELERATOR_BVH, BottomLevelBVH::build_bvh BottomLevelBVH.cpp:72-106 over
+ * BVHBuilders::build_bvh<Triangle> BVHBuilders.h:8-46): three index lists sorted by triangle centroid
+ * (Triangle::get_position, Triangle.h:22-24), full-sweep SAH, leaves below 3 triangles.  Same arguments as rtxh_blas_build;
+ * produces the reference's node array and leaf order for that build mode (checked against a reference dump).            */
+int rtxh_blas_build_reference_bvh(const float * positions, int32_t triangle_count,
+                                  rtx_bvh_node * nodes_out, int32_t * node_count_out, int32_t * order_out);
+
 /* Appends the box-filter mip chain to level 0 (texels_rgb holds w*h float3 on entry and must have
  * room for w*h + w*h/3 + 1 texels); fills desc like Texture::load.                               */
 int rtxh_texture_mips(float * texels_rgb, int32_t width, int32_t height, rtx_texture_desc * desc, int64_t * texel_count_out);
@@ -68,6 +77,18 @@ typedef struct rtxh_mesh {
 } rtxh_mesh;
 int rtxh_atrium_generate(uint32_t seed, int32_t detail, rtxh_mesh * out);   /* allocates; free with rtxh_mesh_free */
 int rtxh_mesh_free(rtxh_mesh * m);
+
+/* OBJ + MTL -> the triangle soup and material list OBJLoader::load_obj builds (OBJLoader.cpp:8-41,70-187).
+ * materials[i].texture_id >= 0 means texture_names + i*RTXH_TEXNAME_MAX holds the map_Kd path (directory of the OBJ
+ * prepended, as OBJLoader.cpp:21 does); decoding the image is left to the caller (Texture::load, Texture.cpp:30-129).   */
+#define RTXH_TEXNAME_MAX 512
+typedef struct rtxh_obj {
+    rtxh_mesh      mesh;            /* material_ids are local to `materials` */
+    rtx_material * materials;       /* mesh.material_count entries */
+    char *         texture_names;   /* mesh.material_count * RTXH_TEXNAME_MAX bytes */
+} rtxh_obj;
+int rtxh_obj_load(const char * path, rtxh_obj * out);                        /* allocates; free with rtxh_obj_free */
+int rtxh_obj_free(rtxh_obj * o);
 
 #ifdef __cplusplus
 }

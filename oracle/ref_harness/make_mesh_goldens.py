@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Fixtures for the OBJ loader and the reference-topology BLAS builder (build container only).
+
+For each small mesh of the reference's Data/ directory: run the REAL reference built with
+MESH_ACCELERATOR_BVH (oracle/_ref/refdump_*_bvh) in a fresh scratch directory (no stale .bvh caches),
+and store the BottomLevelBVH it built (nodes + flattened hot / cold triangles + material table) next to
+a copy of the OBJ / MTL data files under tests/golden/meshes/.  tests/test_obj_loader.py then checks that
+host.load_obj + build_blas(reference_bvh=True) reproduce those arrays bit for bit.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(REPO, "cpu-raytracer_amd"))
+os.environ["RTX_REF_WORK"] = "/tmp/rtx_ref_work_bvh"
+sys.path.insert(0, HERE)
+import make_goldens as mg  # noqa: E402
+from pyrtx import scene_io as sio  # noqa: E402
+
+MESHES = ["Cube", "Diamond", "icosphere", "Concave", "Torus", "Monkey", "Rock"]
+OUT = os.path.join(REPO, "tests", "golden", "meshes")
+
+
+def main():
+    shutil.rmtree(mg.WORK, ignore_errors=True)
+    mg.stage()
+    os.makedirs(OUT, exist_ok=True)
+    for m in MESHES:
+        script = os.path.join(mg.WORK, f"mesh_{m}.txt")
+        with open(script, "w") as f:
+            f.write(f"size 32 32\nbounces 0\nmesh ./Data/{m}.obj 0 0 0\ndir 1 1 1 0 -1 0\ncamera 0 0 -5 0 0 0 1\n")
+        out = mg.run_ref("s0_m1_b3_t2_bvh", script, "mesh_" + m)
+        sc = sio.load_scene(os.path.join(out, "scene.rtxs"))
+        b = sc.blas[0]
+        mats = sc.materials[b.material_offset:]
+        np.savez_compressed(os.path.join(OUT, m + ".ref_bvh.npz"), nodes=b.nodes, tri_hot=b.tri_hot, tri_cold=b.tri_cold,
+                            materials=mats, source_triangles=np.int32(b.source_triangle_count))
+        for ext in (".obj", ".mtl"):
+            src = os.path.join("/root/reference/Data", m + ext)
+            if os.path.exists(src):
+                shutil.copy(src, os.path.join(OUT, m + ext))
+        print(m, "tris", b.source_triangle_count, "refs", len(b.tri_hot), "nodes", len(b.nodes), "materials", len(mats))
+
+
+if __name__ == "__main__":
+    main()
