@@ -1,0 +1,68 @@
+"""Parity at BASELINE.json's full sizes (1920x1080): whole frames against the oracle, plus size-independent properties
+(tile shards assemble to the full frame, shard statistics add up, rendering is idempotent)."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from pyrtx import api as a
+    a.load_library()
+    return a
+
+
+def test_cfg3_atrium_1080p_whole_frame_vs_oracle(api):
+    """BASELINE configs[2] stand-in at full size: 255 296 triangles, 3 lights, depth 3, 2 073 600 pixels, 10.3 M rays."""
+    import orc
+    from pyrtx import host
+    sc = host.atrium_scene(1920, 1080, 3, detail=1)
+    r = api.Renderer(sc)
+    out = r.render()
+    ref = orc.OracleScene(sc).render(threads=64)
+    assert out["stats"] == ref["stats"] == {"primary": 2073600, "shadow": 7657752, "reflection": 587842, "refraction": 20050}
+    d = np.abs(out["rgb"].astype(np.float64) - ref["rgb"].astype(np.float64))
+    assert np.nanmax(d) < 1e-4
+    assert (d.max(axis=-1) > 0).sum() < 64                      # only expf (Beer) pixels may differ, by ~1 ulp
+    assert np.array_equal(out["packed"], ref["packed"])
+    # idempotence + shard properties on the same context
+    again = r.render()
+    assert np.array_equal(again["rgb"].view(np.uint32), out["rgb"].view(np.uint32))
+    r2 = api.Renderer(sc)
+    total = {k: 0 for k in out["stats"]}
+    for g in range(8):                                           # the 8-GPU tile partition, rendered shard by shard on one GPU
+        n = (sc.tile_count - g + 7) // 8
+        r2.render_async(g, 8, n)
+        st, _ = r2.stats()
+        for k in total:
+            total[k] += st[k]
+    rgb, packed = r2.framebuffer()
+    assert total == out["stats"]
+    assert np.array_equal(rgb.view(np.uint32), out["rgb"].view(np.uint32)) and np.array_equal(packed, out["packed"])
+
+
+def test_cfg5_tori16_1080p_dynamic_frames_vs_oracle(api):
+    """BASELINE configs[4]: 16 instanced tori + dielectric spheres + EWA-textured plane at 1920x1080, TLAS rebuilt and
+    re-uploaded every frame (host library), three consecutive frames against the oracle."""
+    import orc
+    from test_dynamic_frames import frame_state
+    from pyrtx import host
+    sc, g, inst, nodes, idx = frame_state("tori16", 1)
+    sc.config["width"] = 1920; sc.config["height"] = 1080
+    # camera basis for the new resolution from the shipped SCENE_DYNAMIC camera (Scene.cpp:69-70)
+    fov = float(np.float32(110.0) * np.float32(3.14159265359) * np.float32(0.00555555555))
+    sc.camera = host.camera_basis(1920, 1080, fov, (-4.694016, 6.446100, -0.572288), (0.268476, 0.423740, -0.133092, 0.854779))
+    r = api.Renderer(sc)
+    for f in (1, 2, 3):
+        _, _, inst, nodes, idx = frame_state("tori16", f)
+        sc.instances, sc.tlas_nodes, sc.tlas_indices = inst, nodes, idx
+        r.set_frame(sc)
+        out = r.render()
+        ref = orc.OracleScene(sc).render(threads=64)
+        assert out["stats"] == ref["stats"] and out["stats"]["refraction"] > 0
+        d = np.abs(out["rgb"].astype(np.float64) - ref["rgb"].astype(np.float64))
+        assert np.nanmax(d) < 1e-4, f
+        assert np.array_equal(out["packed"], ref["packed"]), f
