@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="atrium", choices=["atrium", "monkey", "tori16", "materials"])
     ap.add_argument("--detail", type=int, default=1)
+    ap.add_argument("--accel", choices=["sbvh", "bvh", "binned"], default="sbvh",
+                    help="BLAS builder for the atrium: the reference's SBVH restated (default, BASELINE configs[2]), its plain BVH, or this repo's binned SAH")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget (0 disables)")
@@ -87,8 +89,9 @@ def main():
 
     # ---- scene (built on the host by this repo's own tools; identical on every rank) ----------------
     if args.workload == "atrium":
-        sc = host.atrium_scene(args.width, args.height, bounces=3, detail=args.detail)
-        workload = (f"atrium-{sc.triangle_refs()}tri Sponza-class stand-in (sponza.obj absent from the reference mount) "
+        sc = host.atrium_scene(args.width, args.height, bounces=3, detail=args.detail, accel=args.accel)
+        workload = (f"atrium-{sc.blas[0].source_triangle_count}tri Sponza-class stand-in (sponza.obj absent from the reference mount), "
+                    f"{args.accel.upper()} ({len(sc.blas[0].tri_hot)} refs, {len(sc.blas[0].nodes)} nodes), "
                     f"{args.width}x{args.height}, 3 lights, reflect/refract depth 3, anisotropic mips")
     else:
         sys.path.insert(0, os.path.join(REPO, "tests"))

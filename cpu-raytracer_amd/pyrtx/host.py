@@ -19,7 +19,7 @@ from .ctypes_structs import RtxCamera, RtxTextureDesc
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "host", "librtx_host.so")
 EXPORTS = ["rtxh_camera_basis", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
-           "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_texture_mips", "rtxh_atrium_generate", "rtxh_mesh_free",
+           "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_blas_build_reference_sbvh", "rtxh_texture_mips", "rtxh_atrium_generate", "rtxh_mesh_free",
            "rtxh_obj_load", "rtxh_obj_free"]
 
 PI = np.float32(3.14159265359)          # Util.h:8
@@ -54,6 +54,7 @@ def lib():
         l.rtxh_tlas_build.argtypes = [vp, vp, vp, vp, vp, C.POINTER(i32)]
         l.rtxh_blas_build.argtypes = [vp, i32, i32, vp, C.POINTER(i32), vp]
         l.rtxh_blas_build_reference_bvh.argtypes = [vp, i32, vp, C.POINTER(i32), vp]
+        l.rtxh_blas_build_reference_sbvh.argtypes = [vp, i32, vp, i32, C.POINTER(i32), vp, i32, C.POINTER(i32)]
         l.rtxh_obj_load.argtypes = [C.c_char_p, C.POINTER(RtxhObj)]
         l.rtxh_obj_free.argtypes = [C.POINTER(RtxhObj)]
         l.rtxh_texture_mips.argtypes = [vp, i32, i32, C.POINTER(RtxTextureDesc), C.POINTER(C.c_int64)]
@@ -148,25 +149,40 @@ def load_obj(path: str):
 
 
 def build_blas(positions: np.ndarray, normals: np.ndarray, texcoords: np.ndarray, material_ids: np.ndarray,
-               material_offset: int, bins: int = 32, reference_bvh: bool = False) -> sio.Blas:
+               material_offset: int, bins: int = 32, reference_bvh: bool = False, reference_sbvh: bool = False) -> sio.Blas:
     """Triangle soup (n,3,3) + per-vertex normals (n,3,3) + texcoords (n,3,2) -> flattened BLAS
-    (TriangleHot / TriangleCold as OBJLoader.cpp:156-175 fills them)."""
+    (TriangleHot / TriangleCold as OBJLoader.cpp:156-175 fills them, in leaf order as BottomLevelBVH::flatten :196-212)."""
     pos = _f32(positions).reshape(-1, 9)
     n = pos.shape[0]
-    nodes = np.zeros(2 * n, sio.BVH_NODE)
-    order = np.zeros(n, np.int32)
     nc = C.c_int32()
-    if reference_bvh:     # the reference's MESH_ACCELERATOR_BVH topology (BVHBuilders.h:8-46)
-        rc = lib().rtxh_blas_build_reference_bvh(pos.ctypes.data, n, nodes.ctypes.data, C.byref(nc), order.ctypes.data)
-    else:                 # this repo's binned-SAH builder
-        rc = lib().rtxh_blas_build(pos.ctypes.data, n, bins, nodes.ctypes.data, C.byref(nc), order.ctypes.data)
-    assert rc == 0, rc
+    if reference_sbvh:    # the reference's default MESH_ACCELERATOR_SBVH topology (BVHBuilders.h:48-329): leaves may share triangles
+        cap = 2 * n
+        while True:
+            nodes = np.zeros(2 * cap, sio.BVH_NODE)
+            order = np.zeros(cap, np.int32)
+            oc = C.c_int32()
+            rc = lib().rtxh_blas_build_reference_sbvh(pos.ctypes.data, n, nodes.ctypes.data, len(nodes), C.byref(nc),
+                                                      order.ctypes.data, cap, C.byref(oc))
+            if rc != 4:   # RTX_ERR_LIMIT: more duplicated references than the reference's own 2n arrays hold
+                break
+            cap *= 2
+        assert rc == 0, rc
+        order = order[:oc.value]
+    else:
+        nodes = np.zeros(2 * n, sio.BVH_NODE)
+        order = np.zeros(n, np.int32)
+        if reference_bvh:     # the reference's MESH_ACCELERATOR_BVH topology (BVHBuilders.h:8-46)
+            rc = lib().rtxh_blas_build_reference_bvh(pos.ctypes.data, n, nodes.ctypes.data, C.byref(nc), order.ctypes.data)
+        else:                 # this repo's binned-SAH builder
+            rc = lib().rtxh_blas_build(pos.ctypes.data, n, bins, nodes.ctypes.data, C.byref(nc), order.ctypes.data)
+        assert rc == 0, rc
+    m = len(order)
     p = pos.reshape(n, 3, 3)[order]
     nr = _f32(normals).reshape(n, 3, 3)[order]
     uv = _f32(texcoords).reshape(n, 3, 2)[order]
-    hot = np.zeros(n, sio.TRI_HOT)
+    hot = np.zeros(m, sio.TRI_HOT)
     hot["position_0"] = p[:, 0]; hot["position_edge_1"] = p[:, 1] - p[:, 0]; hot["position_edge_2"] = p[:, 2] - p[:, 0]
-    cold = np.zeros(n, sio.TRI_COLD)
+    cold = np.zeros(m, sio.TRI_COLD)
     cold["tex_coord_0"] = uv[:, 0]; cold["tex_coord_edge_1"] = uv[:, 1] - uv[:, 0]; cold["tex_coord_edge_2"] = uv[:, 2] - uv[:, 0]
     cold["normal_0"] = nr[:, 0]; cold["normal_edge_1"] = nr[:, 1] - nr[:, 0]; cold["normal_edge_2"] = nr[:, 2] - nr[:, 0]
     cold["material_id"] = np.asarray(material_ids, np.int32)[order]
@@ -341,9 +357,12 @@ def atrium_materials(nmat: int) -> np.ndarray:
 
 
 def atrium_scene(width: int = 1920, height: int = 1080, bounces: int = 3, detail: int = 1, seed: int = 0x5EED0003,
-                 mip_filter: int = 1, bins: int = 32) -> sio.Scene:
+                 mip_filter: int = 1, bins: int = 32, accel: str = "sbvh") -> sio.Scene:
     """BASELINE.json configs[2]: Sponza-class (255 296 triangles at detail 1) stand-in, 3 lights,
-    reflect/refract depth 3, anisotropic mip filter (the shipped default, Config.h:53)."""
+    reflect/refract depth 3, anisotropic mip filter (the shipped default, Config.h:53).
+    accel: "sbvh" = the reference's default builder restated (MESH_ACCELERATOR_SBVH, Config.h:35), "bvh" = its
+    non-spatial builder, "binned" = this repo's own binned-SAH builder."""
+    assert accel in ("sbvh", "bvh", "binned"), accel
     pos, nrm, uv, mid, nmat = atrium_mesh(seed, detail)
     sc = sio.Scene()
     sc.config = make_config(width, height, bounces, mip_filter=mip_filter)
@@ -353,7 +372,7 @@ def atrium_scene(width: int = 1920, height: int = 1080, bounces: int = 3, detail
     mats["texture_id"] = -1; mats["index_of_refraction"] = 1.0
     mats[1:] = atrium_materials(nmat)
     sc.materials = mats
-    sc.blas = [build_blas(pos, nrm, uv, mid, material_offset=1, bins=bins)]
+    sc.blas = [build_blas(pos, nrm, uv, mid, material_offset=1, bins=bins, reference_sbvh=accel == "sbvh", reference_bvh=accel == "bvh")]
     root = sc.blas[0].nodes[0]
     inst, mn, mx = instance_update((0, 0, 0), (0, 0, 0, 1), root["aabb_min"], root["aabb_max"], 0)
     sc.instances = inst

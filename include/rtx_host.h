@@ -18,6 +18,8 @@
  *                            reference's node convention + flattened leaf order
  *                            (BVHNode.h:10-28, BottomLevelBVH.cpp:196-212)
  *   rtxh_blas_build_reference_bvh   the reference's non-spatial BLAS builder, node for node (BVHBuilders.h:8-46)
+ *   rtxh_blas_build_reference_sbvh  the reference's DEFAULT BLAS builder (MESH_ACCELERATOR_SBVH, Config.h:35): spatial
+ *                            splits + reference unsplitting, node for node     BVHBuilders.h:48-329, BVHPartitions.h:117-377
  *   rtxh_obj_load            OBJLoader::load_obj / load_mtl                 OBJLoader.cpp:8-187
  *   rtxh_texture_mips        Texture::load's box-filter mip chain          Texture.cpp:76-117
  *   rtxh_atrium_*            seeded procedural stand-in for the absent Sponza mesh
@@ -61,6 +63,16 @@ int rtxh_blas_build(const float * positions, int32_t triangle_count, int32_t bin
  * produces the reference's node array and leaf order for that build mode (checked against a reference dump).            */
 int rtxh_blas_build_reference_bvh(const float * positions, int32_t triangle_count,
                                   rtx_bvh_node * nodes_out, int32_t * node_count_out, int32_t * order_out);
+
+/* The reference's SBVH builder (MESH_ACCELERATOR_SBVH, the shipped default: BottomLevelBVH::build_sbvh BottomLevelBVH.cpp:108-147 over
+ * BVHBuilders::build_sbvh BVHBuilders.h:48-329, BVHPartitions::partition_object / partition_spatial BVHPartitions.h:117-377).
+ * A triangle may be referenced from several leaves, so the flattened order is longer than the mesh: order_out receives
+ * *order_count_out (>= triangle_count) source-triangle ids, nodes_out *node_count_out nodes.  The reference sizes both
+ * arrays at 2 * triangle_count and overruns them beyond that; here a mesh that needs more than the capacities given returns
+ * RTX_ERR_LIMIT (call again with larger arrays).  Output checked bit for bit against trees built by the reference.            */
+int rtxh_blas_build_reference_sbvh(const float * positions, int32_t triangle_count,
+                                   rtx_bvh_node * nodes_out, int32_t node_capacity, int32_t * node_count_out,
+                                   int32_t * order_out, int32_t order_capacity, int32_t * order_count_out);
 
 /* Appends the box-filter mip chain to level 0 (texels_rgb holds w*h float3 on entry and must have
  * room for w*h + w*h/3 + 1 texels); fills desc like Texture::load.                               */

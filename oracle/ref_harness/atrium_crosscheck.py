@@ -24,50 +24,26 @@ REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, os.path.join(REPO, "cpu-raytracer_amd"))
 sys.path.insert(0, os.path.join(REPO, "oracle"))
 sys.path.insert(0, HERE)
-from pyrtx import host, scene_io as sio  # noqa: E402
+from pyrtx import host, obj_export, scene_io as sio  # noqa: E402
 import make_goldens as mg  # noqa: E402
 import orc  # noqa: E402
 
 
-def write_tga(path, img_u8):
-    h, w, _ = img_u8.shape
-    hdr = bytearray(18); hdr[2] = 2; hdr[12] = w & 255; hdr[13] = w >> 8; hdr[14] = h & 255; hdr[15] = h >> 8; hdr[16] = 24; hdr[17] = 0x20   # top-left origin
-    with open(path, "wb") as f:
-        f.write(bytes(hdr)); f.write(img_u8[:, :, ::-1].tobytes())
+def reachable_nodes(nodes):
+    """Mask of the nodes a traversal can reach (the reference leaves index 1 and abandoned child pairs unwritten)."""
+    cnt = nodes["count"]; lf = nodes["left_or_first"]
+    seen = np.zeros(len(nodes), bool); stack = [0]
+    while stack:
+        k = stack.pop(); seen[k] = True
+        if (int(cnt[k]) & 0x3fffffff) == 0:
+            stack += [int(lf[k]), int(lf[k]) + 1]
+    return seen
 
 
 def export(detail, seed, d):
-    os.makedirs(d, exist_ok=True)
     pos, nrm, uv, mid, nmat = host.atrium_mesh(seed, detail)
-    mats = host.atrium_materials(nmat)
-    for i, img in enumerate(host.procedural_texture_images(seed)):
-        write_tga(os.path.join(d, f"tex{i}.tga"), img)
-    with open(os.path.join(d, "atrium.mtl"), "w") as f:
-        for i, m in enumerate(mats):
-            f.write(f"newmtl m{i}\nKd {m['diffuse'][0]:.9g} {m['diffuse'][1]:.9g} {m['diffuse'][2]:.9g}\n"
-                    f"Ks {m['reflection'][0]:.9g} {m['reflection'][1]:.9g} {m['reflection'][2]:.9g}\n"
-                    f"Kt {m['transmittance'][0]:.9g} {m['transmittance'][1]:.9g} {m['transmittance'][2]:.9g}\nNi {m['index_of_refraction']:.9g}\n")
-            if m["texture_id"] >= 0:
-                f.write(f"map_Kd tex{int(m['texture_id'])}.tga\n")
-            f.write("\n")
-    n = len(pos)
-    with open(os.path.join(d, "atrium.obj"), "w") as f:
-        f.write("mtllib atrium.mtl\n")
-        p = pos.reshape(-1, 3); nn = nrm.reshape(-1, 3); t = uv.reshape(-1, 2).copy()
-        t[:, 1] = 1.0 - t[:, 1]                                   # the loader flips v back (OBJLoader.cpp:139-141)
-        f.write("".join(f"v {a:.9g} {b:.9g} {c:.9g}\n" for a, b, c in p))
-        f.write("".join(f"vt {a:.9g} {b:.9g}\n" for a, b in t))
-        f.write("".join(f"vn {a:.9g} {b:.9g} {c:.9g}\n" for a, b, c in nn))
-        order = np.argsort(mid, kind="stable")
-        cur = -1
-        out = []
-        for k in order:
-            if mid[k] != cur:
-                cur = int(mid[k]); out.append(f"usemtl m{cur}\n")
-            a = 3 * k + 1
-            out.append(f"f {a}/{a}/{a} {a+1}/{a+1}/{a+1} {a+2}/{a+2}/{a+2}\n")
-        f.write("".join(out))
-    return n
+    obj_export.write_obj(d, "atrium", pos, nrm, uv, mid, host.atrium_materials(nmat), host.procedural_texture_images(seed))
+    return len(pos)
 
 
 def main():
@@ -98,22 +74,35 @@ def main():
     exact = bool(np.array_equal(o["rgb"].view(np.uint32), ref_rgb.view(np.uint32)) and np.array_equal(o["packed"], ref_packed))
     stats_ok = [o["stats"][k] for k in ("primary", "shadow", "reflection", "refraction")] == [st["primary"], st["shadow"], st["reflection"], st["refraction"]]
 
-    sc_own = host.atrium_scene(W, H, 3, detail=detail, seed=seed)
-    own = orc.OracleScene(sc_own).render(threads=8)
-    d_rgb = np.abs(own["rgb"].astype(np.float64) - ref_rgb.astype(np.float64))
     def per_ray(w):
         return {"nodes_per_closest_ray": round((w["blas_nodes_closest"]) / w["closest_rays"], 2), "tris_per_closest_ray": round(w["tri_tests_closest"] / w["closest_rays"], 2),
                 "nodes_per_shadow_ray": round(w["blas_nodes_any"] / max(w["any_rays"], 1), 2), "tris_per_shadow_ray": round(w["tri_tests_any"] / max(w["any_rays"], 1), 2)}
+
+    def own_tree(accel):
+        sc_own = host.atrium_scene(W, H, 3, detail=detail, seed=seed, accel=accel)
+        own = orc.OracleScene(sc_own).render(threads=8)
+        d_rgb = np.abs(own["rgb"].astype(np.float64) - ref_rgb.astype(np.float64))
+        return {"bvh_nodes": int(len(sc_own.blas[0].nodes)), "references": int(len(sc_own.blas[0].tri_hot)), "stats": own["stats"], "traversal": per_ray(own["work"]),
+                "pixels_differing_vs_reference": int((d_rgb.max(axis=-1) > 0).sum()), "pixels_differing_gt_1e-4": int((d_rgb.max(axis=-1) > 1e-4).sum()),
+                "max_abs": float(np.nanmax(d_rgb)), "packed_mismatch": int((own["packed"] != ref_packed).sum()),
+                "note": "OBJ text round-trips vertex data through tinyobjloader's float parser, so geometry is equal only to ~1 ulp between the two scenes"}
     res = {
         "workload": f"atrium detail {detail}: {n} triangles, {W}x{H}, depth 3, 3 lights",
         "reference": {"render_tile_ms_1thread_lane1": st["render_tile_ms_1thread"], "stats": [st["primary"], st["shadow"], st["reflection"], st["refraction"]],
                       "sbvh_nodes": int(len(sc_ref.blas[0].nodes)), "sbvh_refs": int(len(sc_ref.blas[0].tri_hot)), "wall_s_incl_sbvh_build": round(t_ref, 1)},
         "oracle_on_reference_sbvh": {"bit_exact_rgb_and_packed": exact, "stats_equal": stats_ok, "traversal": per_ray(o["work"])},
-        "oracle_on_own_bvh": {"bvh_nodes": int(len(sc_own.blas[0].nodes)), "stats": own["stats"], "traversal": per_ray(own["work"]),
-                              "pixels_differing_vs_reference": int((d_rgb.max(axis=-1) > 0).sum()), "pixels_differing_gt_1e-4": int((d_rgb.max(axis=-1) > 1e-4).sum()),
-                              "max_abs": float(np.nanmax(d_rgb)), "packed_mismatch": int((own["packed"] != ref_packed).sum()),
-                              "note": "OBJ text round-trips vertex data through tinyobjloader's float parser, so geometry is equal only to ~1 ulp between the two scenes"},
+        "oracle_on_restated_sbvh": own_tree("sbvh"),      # bench default: librtx_host's SBVH on the procedural mesh itself
+        "oracle_on_own_bvh": own_tree("binned"),          # this repo's binned-SAH builder
     }
+    # fixture for tests/test_sbvh.py: digest of the SBVH the reference built for this mesh (its own .bvh cache file)
+    import hashlib
+    rb = host.load_bvh_cache(os.path.join(d, "atrium.obj.bvh"))
+    digest = {"detail": detail, "seed": seed, "source_triangles": n, "nodes": int(len(rb.nodes)), "references": int(len(rb.tri_hot)),
+              "reachable_nodes_sha256": hashlib.sha256(rb.nodes[reachable_nodes(rb.nodes)].tobytes()).hexdigest(),
+              "tri_hot_sha256": hashlib.sha256(rb.tri_hot.tobytes()).hexdigest(),
+              "tri_cold_sha256": hashlib.sha256(rb.tri_cold.tobytes()).hexdigest(),
+              "made_by": "oracle/ref_harness/atrium_crosscheck.py from the .bvh cache written by the real reference (MESH_ACCELERATOR_SBVH)"}
+    json.dump(digest, open(os.path.join(REPO, "tests", "golden", f"atrium_d{detail}_ref_sbvh.json"), "w"), indent=1)
     os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
     json.dump(res, open(os.path.join(REPO, "profiles", "r01_atrium_crosscheck.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))

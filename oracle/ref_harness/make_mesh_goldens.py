@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Fixtures for the OBJ loader and the reference-topology BLAS builder (build container only).
+"""Fixtures for the OBJ loader and the reference-topology BLAS builders (build container only).
 
-For each small mesh of the reference's Data/ directory: run the REAL reference built with
-MESH_ACCELERATOR_BVH (oracle/_ref/refdump_*_bvh) in a fresh scratch directory (no stale .bvh caches),
-and store the BottomLevelBVH it built (nodes + flattened hot / cold triangles + material table) next to
-a copy of the OBJ / MTL data files under tests/golden/meshes/.  tests/test_obj_loader.py then checks that
-host.load_obj + build_blas(reference_bvh=True) reproduce those arrays bit for bit.
+For each small mesh of the reference's Data/ directory: run the REAL reference, built once with
+MESH_ACCELERATOR_BVH (oracle/_ref/refdump_*_bvh) and once with the shipped default MESH_ACCELERATOR_SBVH
+(oracle/_ref/refdump_s0_m1_b3_t2), each in its own fresh scratch directory (the two modes share one `.bvh`
+cache file name), and store the BottomLevelBVH it built (nodes + flattened hot / cold triangles + material
+table) as <mesh>.ref_bvh.npz / <mesh>.ref_sbvh.npz next to a copy of the OBJ / MTL data files under
+tests/golden/meshes/.  tests/test_obj_loader.py and tests/test_sbvh.py then check that host.load_obj +
+build_blas(reference_bvh=True / reference_sbvh=True) reproduce those arrays bit for bit.
 """
 import os
 import shutil
@@ -26,7 +28,8 @@ MESHES = ["Cube", "Diamond", "icosphere", "Concave", "Torus", "Monkey", "Rock"]
 OUT = os.path.join(REPO, "tests", "golden", "meshes")
 
 
-def main():
+def dump(variant, work, suffix):
+    mg.WORK = work
     shutil.rmtree(mg.WORK, ignore_errors=True)
     mg.stage()
     os.makedirs(OUT, exist_ok=True)
@@ -34,17 +37,22 @@ def main():
         script = os.path.join(mg.WORK, f"mesh_{m}.txt")
         with open(script, "w") as f:
             f.write(f"size 32 32\nbounces 0\nmesh ./Data/{m}.obj 0 0 0\ndir 1 1 1 0 -1 0\ncamera 0 0 -5 0 0 0 1\n")
-        out = mg.run_ref("s0_m1_b3_t2_bvh", script, "mesh_" + m)
+        out = mg.run_ref(variant, script, "mesh_" + m)
         sc = sio.load_scene(os.path.join(out, "scene.rtxs"))
         b = sc.blas[0]
         mats = sc.materials[b.material_offset:]
-        np.savez_compressed(os.path.join(OUT, m + ".ref_bvh.npz"), nodes=b.nodes, tri_hot=b.tri_hot, tri_cold=b.tri_cold,
+        np.savez_compressed(os.path.join(OUT, m + suffix), nodes=b.nodes, tri_hot=b.tri_hot, tri_cold=b.tri_cold,
                             materials=mats, source_triangles=np.int32(b.source_triangle_count))
         for ext in (".obj", ".mtl"):
             src = os.path.join("/root/reference/Data", m + ext)
             if os.path.exists(src):
                 shutil.copy(src, os.path.join(OUT, m + ext))
         print(m, "tris", b.source_triangle_count, "refs", len(b.tri_hot), "nodes", len(b.nodes), "materials", len(mats))
+
+
+def main():
+    dump("s0_m1_b3_t2_bvh", "/tmp/rtx_ref_work_bvh", ".ref_bvh.npz")
+    dump("s0_m1_b3_t2", "/tmp/rtx_ref_work_sbvh", ".ref_sbvh.npz")
 
 
 if __name__ == "__main__":

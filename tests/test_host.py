@@ -85,7 +85,8 @@ def test_atrium_scene_is_deterministic_and_renders_on_the_oracle():
     a = host.atrium_scene(160, 90, 3, detail=0)
     b = host.atrium_scene(160, 90, 3, detail=0)
     assert a.blas[0].nodes.tobytes() == b.blas[0].nodes.tobytes() and a.blas[0].tri_hot.tobytes() == b.blas[0].tri_hot.tobytes()
-    assert a.triangle_refs() == 63992 and len(a.materials) == 26
+    assert a.blas[0].source_triangle_count == 63992 and a.triangle_refs() >= 63992 and len(a.materials) == 26   # SBVH may duplicate references
+    assert host.atrium_scene(160, 90, 3, detail=0, accel="binned").triangle_refs() == 63992
     out = orc.OracleScene(a).render(threads=8)
     assert out["stats"]["primary"] == 160 * 90 and out["stats"]["shadow"] > 0 and out["stats"]["reflection"] > 0 and out["stats"]["refraction"] > 0
     assert not np.isnan(out["rgb"]).any()
