@@ -5,13 +5,21 @@
 //     loop { scene.update(dt);  for every tile: raytracer.render_tile(window, x, y, w, h, stats);  window.draw_quad(); }
 // The classes below keep those names, argument meanings and the Config.h knob names, and forward to the C ABI
 // (include/rtx.h on the GPU, include/rtx_host.h for the Scene::update arithmetic).  Scene *content* is data: instead of
-// the reference's hard-coded constructors (Scene.cpp:6-131) a Scene is filled from arrays or an RTXS scene file.
+// the reference's hard-coded constructors (Scene.cpp:6-131) a Scene is filled from arrays, an RTXS scene file, or asset
+// files: Scene::load_mesh / load_texture / add_mesh / add_sphere / add_plane do what BottomLevelBVH::load, Texture::load,
+// Mesh::init and the Primitive constructors do in the reference, and load_script reads the scene scripts of
+// oracle/ref_harness (the same text drives the real reference in the parity tests).
 //
 // Header-only; link with librtx_hip.so and librtx_host.so.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -105,6 +113,83 @@ public:
     ~Scene() { if (tlas_) rtxh_tlas_destroy(tlas_); if (ctx_) rtx_destroy(ctx_); }
     Scene(const Scene &) = delete; Scene & operator=(const Scene &) = delete;
 
+    // ---- assets: the reference's global caches (bvh_cache BottomLevelBVH.cpp:16, texture_cache Texture.cpp:11, MaterialBuffer) ----
+    int MESH_ACCELERATOR = 1;                                   // Config.h:32-35: 0 = BVH, 1 = SBVH
+    int reserve_material() {                                    // MaterialBuffer::reserve with Material's defaults (Material.h:7-14,32-40)
+        ensure_default_material();
+        rtx_material m; std::memset(&m, 0, sizeof(m));
+        m.diffuse[0] = m.diffuse[1] = m.diffuse[2] = 1.0f; m.texture_id = -1; m.index_of_refraction = 1.0f;
+        materials.push_back(m);
+        return (int)materials.size() - 1;
+    }
+    int load_texture(const std::string & path) {                // Texture::load, Texture.cpp:30-129
+        auto it = texture_by_file_.find(path);
+        if (it != texture_by_file_.end()) return it->second;
+        float * tx = nullptr; int64_t count = 0; Texture t;
+        check(rtxh_texture_load(path.c_str(), config.TEXTURE_SAMPLE_MODE == RTX_TEXTURE_MIPMAP, &tx, &count, &t.desc), ("Texture::load " + path).c_str());
+        t.texels.assign(tx, tx + 3 * count);
+        rtxh_texture_free(tx);
+        textures.push_back(std::move(t));
+        return texture_by_file_[path] = (int)textures.size() - 1;
+    }
+    int load_mesh(const std::string & obj_path) {               // BottomLevelBVH::load, BottomLevelBVH.cpp:18-58 (without the .bvh disk cache)
+        auto it = blas_by_file_.find(obj_path);
+        if (it != blas_by_file_.end()) return it->second;
+        ensure_default_material();
+        rtxh_obj o; std::memset(&o, 0, sizeof(o));
+        check(rtxh_obj_load(obj_path.c_str(), &o), ("OBJLoader::load_obj " + obj_path).c_str());
+        Blas b; b.material_offset = (int)materials.size();      // OBJLoader.cpp:9
+        for (int i = 0; i < o.mesh.material_count; i++) {
+            rtx_material m = o.materials[i];
+            m.texture_id = m.texture_id >= 0 ? load_texture(o.texture_names + (size_t)i * RTXH_TEXNAME_MAX) : -1;
+            materials.push_back(m);
+        }
+        const int n = o.mesh.triangle_count;
+        std::vector<int32_t> order; int node_count = 0, refs = n;
+        for (int cap = 2 * n;; cap *= 2) {
+            b.nodes.assign(2 * (size_t)cap, rtx_bvh_node()); order.assign(cap, 0);
+            int rc = MESH_ACCELERATOR == 1
+                ? rtxh_blas_build_reference_sbvh(o.mesh.positions, n, b.nodes.data(), (int)b.nodes.size(), &node_count, order.data(), cap, &refs)
+                : rtxh_blas_build_reference_bvh(o.mesh.positions, n, b.nodes.data(), &node_count, order.data());
+            if (rc == RTX_ERR_LIMIT && MESH_ACCELERATOR == 1) continue;
+            if (rc) { rtxh_obj_free(&o); check(rc, "BottomLevelBVH::build"); }
+            break;
+        }
+        b.nodes.resize(node_count);
+        b.hot.resize(refs); b.cold.resize(refs);                // OBJLoader.cpp:156-175 + BottomLevelBVH::flatten :196-212
+        for (int k = 0; k < refs; k++) {
+            const int t = order[k];
+            const float * p = o.mesh.positions + 9 * (size_t)t, * nr = o.mesh.normals + 9 * (size_t)t, * uv = o.mesh.texcoords + 6 * (size_t)t;
+            rtx_triangle_hot & h = b.hot[k]; rtx_triangle_cold & c = b.cold[k];
+            std::memset(&c, 0, sizeof(c));
+            for (int d = 0; d < 3; d++) {
+                h.position_0[d] = p[d]; h.position_edge_1[d] = p[3 + d] - p[d]; h.position_edge_2[d] = p[6 + d] - p[d];
+                c.normal_0[d] = nr[d];  c.normal_edge_1[d] = nr[3 + d] - nr[d]; c.normal_edge_2[d] = nr[6 + d] - nr[d];
+            }
+            for (int d = 0; d < 2; d++) { c.tex_coord_0[d] = uv[d]; c.tex_coord_edge_1[d] = uv[2 + d] - uv[d]; c.tex_coord_edge_2[d] = uv[4 + d] - uv[d]; }
+            c.material_id = o.mesh.material_ids[t];
+        }
+        rtxh_obj_free(&o);
+        blas.push_back(std::move(b));
+        return blas_by_file_[obj_path] = (int)blas.size() - 1;
+    }
+    Mesh & add_mesh(const std::string & obj_path, const float position[3], const float rotation[4]) {   // Mesh::init, Mesh.cpp:5-7
+        Mesh m; m.blas_id = load_mesh(obj_path);
+        std::memcpy(m.position, position, 12); std::memcpy(m.rotation, rotation, 16);
+        meshes.push_back(m);
+        return meshes.back();
+    }
+    rtx_sphere & add_sphere(const float center[3], float radius) {                                      // Sphere::init, Sphere.h:13-16
+        rtx_sphere s; std::memcpy(s.center, center, 12); s.radius_inv = 1.0f / radius; s.radius_squared = radius * radius; s.material_id = reserve_material();
+        spheres.push_back(s);
+        return spheres.back();
+    }
+    PlaneDesc & add_plane(const float position[3], const float rotation[4]) {
+        PlaneDesc p; std::memcpy(p.position, position, 12); std::memcpy(p.rotation, rotation, 16); p.material_id = reserve_material();
+        planes.push_back(p);
+        return planes.back();
+    }
+
     // one-off uploads (the reference does this inside its constructors through global caches)
     void upload() {
         for (size_t i = 0; i < blas.size(); i++)
@@ -154,6 +239,12 @@ public:
     void check(int rc, const char * what) const { if (rc) throw std::runtime_error(std::string(what) + ": " + std::to_string(rc) + " " + rtx_last_error(ctx_)); }
 
 private:
+    void ensure_default_material() {                            // MaterialBuffer::init, Material.h:52-60
+        if (!materials.empty()) return;
+        rtx_material m; std::memset(&m, 0, sizeof(m)); m.texture_id = -1; m.index_of_refraction = 1.0f;
+        materials.push_back(m);
+    }
+    std::map<std::string, int> blas_by_file_, texture_by_file_;
     rtx_ctx * ctx_ = nullptr;
     rtxh_tlas * tlas_ = nullptr; int tlas_n_ = 0; int tlas_node_count_ = 0;
     std::vector<rtx_instance> instances_; std::vector<float> positions_, aabbs_;
@@ -219,6 +310,85 @@ inline void load_rtxs(const std::string & path, Scene & sc, std::vector<rtx_inst
     }
     std::fclose(f);
     for (size_t i = 0; i < sc.meshes.size() && 7 * i + 6 < ipos.size(); i++) { std::memcpy(sc.meshes[i].position, &ipos[7 * i], 12); std::memcpy(sc.meshes[i].rotation, &ipos[7 * i + 3], 16); }
+}
+
+// ---- scene scripts (the description language of oracle/ref_harness/refdump.cpp; the same text drives the real reference) --------
+struct ScriptHeader { int width = 256, height = 256, bounces = 3; };
+inline ScriptHeader peek_script(const std::string & path) {      // size / bounces are needed before the Scene (and its GPU context) exists
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("cannot open " + path);
+    ScriptHeader h; std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream is(line.substr(0, line.find('#'))); std::string w; is >> w;
+        if (w == "size") is >> h.width >> h.height; else if (w == "bounces") is >> h.bounces;
+    }
+    return h;
+}
+
+// Fills `sc` from a script; `./Data/` prefixes resolve against data_dir (the reference's DATA_PATH, Util.h:6).  Synthetic 64x64 sky as
+// in the goldens (the reference's probe files are absent from its repository).
+inline void load_script(const std::string & path, const std::string & data_dir, Scene & sc) {
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("cannot open " + path);
+    auto data = [&](const std::string & p) { return p.rfind("./Data/", 0) == 0 ? data_dir + "/" + p.substr(7) : p; };
+    auto normalize = [](float * v) { float inv = 1.0f / sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] *= inv; v[1] *= inv; v[2] *= inv; };   // Vector3.h:24-31
+    const float PI = 3.14159265359f;                              // Util.h:8
+    struct Edit { std::string target, field; std::vector<std::string> args; };
+    std::vector<Edit> edits;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream is(line.substr(0, line.find('#')));
+        std::vector<std::string> w; for (std::string t; is >> t;) w.push_back(t);
+        if (w.empty()) continue;
+        auto F = [&](size_t i) { return (float)atof(w.at(i).c_str()); };
+        auto quat = [&](size_t i, bool axis_angle, bool present, float * q) {
+            q[0] = q[1] = q[2] = 0; q[3] = 1;
+            if (!present) return;
+            if (axis_angle) { float a[3] = { F(i), F(i + 1), F(i + 2) }; rtxh_quaternion_axis_angle(a, F(i + 3), q); }
+            else { q[0] = F(i); q[1] = F(i + 1); q[2] = F(i + 2); q[3] = F(i + 3); }
+        };
+        const std::string & c = w[0];
+        if (c == "size" || c == "bounces" || c == "nolights" || c == "texprobe") continue;
+        else if (c == "camera" || c == "camera_axis_angle") { sc.camera.position[0] = F(1); sc.camera.position[1] = F(2); sc.camera.position[2] = F(3); quat(4, c == "camera_axis_angle", true, sc.camera.rotation); }
+        else if (c == "ambient") { sc.ambient_lighting[0] = F(1); sc.ambient_lighting[1] = F(2); sc.ambient_lighting[2] = F(3); }
+        else if (c == "mesh" || c == "mesh_axis_angle") { float p[3] = { F(2), F(3), F(4) }, q[4]; quat(5, c == "mesh_axis_angle", w.size() >= 9, q); sc.add_mesh(data(w[1]), p, q); }
+        else if (c == "sphere") { float p[3] = { F(1), F(2), F(3) }; sc.add_sphere(p, F(4)); }
+        else if (c == "plane" || c == "plane_axis_angle") { float p[3] = { F(1), F(2), F(3) }, q[4]; quat(4, c == "plane_axis_angle", w.size() >= 8, q); sc.add_plane(p, q); }
+        else if (c == "point") { rtx_point_light l = { { F(1), F(2), F(3) }, { F(4), F(5), F(6) } }; sc.point_lights.push_back(l); }
+        else if (c == "spot") {                                   // SpotLight.h:12-15
+            rtx_spot_light l; float d[3] = { F(7), F(8), F(9) }; normalize(d);
+            for (int k = 0; k < 3; k++) { l.colour[k] = F(1 + k); l.position[k] = F(4 + k); l.negative_direction[k] = -d[k]; }
+            l.inner_cutoff = cosf((0.5f * F(10)) * PI * 0.00555555555f); l.outer_cutoff = cosf((0.5f * F(11)) * PI * 0.00555555555f);
+            sc.spot_lights.push_back(l);
+        }
+        else if (c == "dir") { rtx_directional_light l; float d[3] = { F(4), F(5), F(6) }; normalize(d); for (int k = 0; k < 3; k++) { l.colour[k] = F(1 + k); l.negative_direction[k] = -d[k]; } sc.directional_lights.push_back(l); }
+        else if (c == "matset") { Edit e; e.target = w.at(1); e.field = w.at(2); e.args.assign(w.begin() + 3, w.end()); edits.push_back(e); }
+        else throw std::runtime_error("scene script command not supported: " + c);
+    }
+    for (const Edit & e : edits) {                                // applied after construction, as the harness does
+        std::vector<std::string> t; { std::istringstream ts(e.target); for (std::string part; std::getline(ts, part, ':');) t.push_back(part); }
+        int id;
+        if (t.at(0) == "mesh") id = sc.blas[sc.meshes.at(atoi(t.at(1).c_str())).blas_id].material_offset + atoi(t.at(2).c_str());
+        else if (t[0] == "sphere") id = sc.spheres.at(atoi(t.at(1).c_str())).material_id;
+        else if (t[0] == "plane") id = sc.planes.at(atoi(t.at(1).c_str())).material_id;
+        else if (t[0] == "global") id = atoi(t.at(1).c_str());
+        else throw std::runtime_error("bad material target " + e.target);
+        rtx_material & m = sc.materials.at(id);
+        auto A = [&](size_t i) { return (float)atof(e.args.at(i).c_str()); };
+        if (e.field == "diffuse") { m.diffuse[0] = A(0); m.diffuse[1] = A(1); m.diffuse[2] = A(2); }
+        else if (e.field == "reflection") { m.reflection[0] = A(0); m.reflection[1] = A(1); m.reflection[2] = A(2); }
+        else if (e.field == "transmittance") { m.transmittance[0] = A(0); m.transmittance[1] = A(1); m.transmittance[2] = A(2); }
+        else if (e.field == "ior") m.index_of_refraction = A(0);
+        else if (e.field == "notexture") m.texture_id = -1;
+        else if (e.field == "texture") m.texture_id = sc.load_texture(data(e.args.at(0)));
+        else throw std::runtime_error("bad matset field " + e.field);
+    }
+    const int n = 64;                                             // the goldens' synthetic sky probe (oracle/ref_harness/make_goldens.py)
+    sc.sky_size = n; sc.sky.resize((size_t)n * n * 3);
+    for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) {
+        float * o = &sc.sky[((size_t)y * n + x) * 3];
+        o[0] = (float)(0.5 + 0.5 * x / n); o[1] = (float)(0.6 + 0.2 * (((x / 8) + (y / 8)) & 1)); o[2] = (float)(0.5 + 0.5 * y / n);
+    }
 }
 
 }  // namespace rtx

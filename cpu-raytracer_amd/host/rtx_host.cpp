@@ -146,6 +146,14 @@ extern "C" int rtxh_instance_update(const float position[3], const float rotatio
     return RTX_OK;
 }
 
+extern "C" int rtxh_quaternion_axis_angle(const float axis[3], float angle, float out[4]) {    // Quaternion::axis_angle, Quaternion.h:26-36
+    if (!axis || !out) return RTX_ERR_INVALID_ARG;
+    float half_angle = 0.5f * angle;
+    float sine = sinf(half_angle);
+    out[0] = axis[0] * sine; out[1] = axis[1] * sine; out[2] = axis[2] * sine; out[3] = cosf(half_angle);
+    return RTX_OK;
+}
+
 extern "C" int rtxh_plane_update(const float position[3], const float rotation[4], int32_t material_id, rtx_plane * out) {
     if (!position || !rotation || !out) return RTX_ERR_INVALID_ARG;
     float w[16];

@@ -18,8 +18,8 @@ from .ctypes_structs import RtxCamera, RtxTextureDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "host", "librtx_host.so")
-EXPORTS = ["rtxh_camera_basis", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
-           "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_blas_build_reference_sbvh", "rtxh_texture_mips", "rtxh_atrium_generate", "rtxh_mesh_free",
+EXPORTS = ["rtxh_camera_basis", "rtxh_quaternion_axis_angle", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
+           "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_blas_build_reference_sbvh", "rtxh_texture_mips", "rtxh_texture_load", "rtxh_texture_free", "rtxh_image_load", "rtxh_image_free", "rtxh_atrium_generate", "rtxh_mesh_free",
            "rtxh_obj_load", "rtxh_obj_free"]
 
 PI = np.float32(3.14159265359)          # Util.h:8
@@ -54,6 +54,11 @@ def lib():
         l.rtxh_tlas_build.argtypes = [vp, vp, vp, vp, vp, C.POINTER(i32)]
         l.rtxh_blas_build.argtypes = [vp, i32, i32, vp, C.POINTER(i32), vp]
         l.rtxh_blas_build_reference_bvh.argtypes = [vp, i32, vp, C.POINTER(i32), vp]
+        l.rtxh_quaternion_axis_angle.argtypes = [vp, C.c_float, vp]
+        l.rtxh_texture_load.argtypes = [C.c_char_p, i32, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64), C.POINTER(RtxTextureDesc)]
+        l.rtxh_texture_free.argtypes = [C.POINTER(C.c_float)]
+        l.rtxh_image_load.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.POINTER(C.c_uint8))]
+        l.rtxh_image_free.argtypes = [C.POINTER(C.c_uint8)]
         l.rtxh_blas_build_reference_sbvh.argtypes = [vp, i32, vp, i32, C.POINTER(i32), vp, i32, C.POINTER(i32)]
         l.rtxh_obj_load.argtypes = [C.c_char_p, C.POINTER(RtxhObj)]
         l.rtxh_obj_free.argtypes = [C.POINTER(RtxhObj)]
@@ -72,11 +77,10 @@ def _f32(a):
 
 def axis_angle(axis: Sequence[float], angle: float) -> np.ndarray:
     """Quaternion::axis_angle, Quaternion.h:24-34 (sinf/cosf in fp32)."""
-    half = np.float32(0.5) * np.float32(angle)
-    s = np.sin(half, dtype=np.float32)
-    c = np.cos(half, dtype=np.float32)
+    out = np.zeros(4, np.float32)
     a = _f32(axis)
-    return np.array([a[0] * s, a[1] * s, a[2] * s, c], np.float32)
+    assert lib().rtxh_quaternion_axis_angle(a.ctypes.data, C.c_float(float(np.float32(angle))), out.ctypes.data) == 0
+    return out
 
 
 def camera_basis(width: int, height: int, fov: float, position, rotation) -> np.ndarray:
@@ -228,6 +232,30 @@ def texture_with_mips(level0_rgb: np.ndarray) -> sio.Texture:
     d = np.zeros(1, sio.TEXTURE_DESC)
     C.memmove(d.ctypes.data, C.byref(desc), C.sizeof(desc))
     return sio.Texture(d, buf[:cnt.value].copy())
+
+
+def load_image(path: str) -> np.ndarray:
+    """PNG / TGA file -> (h, w, 4) uint8 RGBA, decoded like stbi_load(..., STBI_rgb_alpha) at Texture.cpp:40."""
+    w = C.c_int32(); h = C.c_int32(); p = C.POINTER(C.c_uint8)()
+    rc = lib().rtxh_image_load(path.encode(), C.byref(w), C.byref(h), C.byref(p))
+    if rc:
+        raise ValueError(f"rtxh_image_load({path!r}) failed with status {rc}")
+    out = np.ctypeslib.as_array(p, (h.value, w.value, 4)).copy()
+    lib().rtxh_image_free(p)
+    return out
+
+
+def load_texture(path: str, mipmap_mode: bool = True) -> sio.Texture:
+    """Texture::load (Texture.cpp:30-129): decode, sRGB -> linear, box-filter mips when both sides are powers of two."""
+    p = C.POINTER(C.c_float)(); cnt = C.c_int64(); desc = RtxTextureDesc()
+    rc = lib().rtxh_texture_load(path.encode(), 1 if mipmap_mode else 0, C.byref(p), C.byref(cnt), C.byref(desc))
+    if rc:
+        raise ValueError(f"rtxh_texture_load({path!r}) failed with status {rc}")
+    texels = np.ctypeslib.as_array(p, (cnt.value, 3)).copy()
+    lib().rtxh_texture_free(p)
+    d = np.zeros(1, sio.TEXTURE_DESC)
+    C.memmove(d.ctypes.data, C.byref(desc), C.sizeof(desc))
+    return sio.Texture(d, texels)
 
 
 _SRGB_LUT = None

@@ -10,6 +10,7 @@
  *                            (Transform::calc_world_matrix Transform.h:13-43, AABB::transform
  *                             AABB.cpp:55-73, Matrix4::invert Matrix4.h:88-138)
  *   rtxh_plane_update        Plane::update                                Plane.cpp:3-11
+ *   rtxh_quaternion_axis_angle  Quaternion::axis_angle                     Quaternion.h:26-36
  *   rtxh_tlas_*              TopLevelBVH::init / build_bvh                TopLevelBVH.cpp:5-45
  *                            (BVHBuilders::build_bvh<Mesh> BVHBuilders.h:8-46,
  *                             BVHPartitions::{calculate_bounds,partition_sah,split_indices})
@@ -22,6 +23,8 @@
  *                            splits + reference unsplitting, node for node     BVHBuilders.h:48-329, BVHPartitions.h:117-377
  *   rtxh_obj_load            OBJLoader::load_obj / load_mtl                 OBJLoader.cpp:8-187
  *   rtxh_texture_mips        Texture::load's box-filter mip chain          Texture.cpp:76-117
+ *   rtxh_texture_load        Texture::load: PNG / TGA file -> linear float3 texels + mips   Texture.cpp:30-129
+ *   rtxh_image_load          the stbi_load(..., STBI_rgb_alpha) call inside it  Texture.cpp:40
  *   rtxh_atrium_*            seeded procedural stand-in for the absent Sponza mesh
  */
 #ifndef RTX_HOST_H
@@ -40,6 +43,9 @@ int rtxh_camera_basis(int32_t width, int32_t height, float fov, const float posi
 /* Mesh::update: fills out->world / world_inv (blas_id untouched) and the world-space AABB of the instance */
 int rtxh_instance_update(const float position[3], const float rotation[4], const float blas_root_min[3], const float blas_root_max[3],
                          rtx_instance * out, float out_aabb_min[3], float out_aabb_max[3]);
+
+/* Quaternion::axis_angle (Quaternion.h:26-36) with the host libm's sinf / cosf, as the reference evaluates it */
+int rtxh_quaternion_axis_angle(const float axis[3], float angle, float out[4]);
 
 int rtxh_plane_update(const float position[3], const float rotation[4], int32_t material_id, rtx_plane * out);
 
@@ -77,6 +83,18 @@ int rtxh_blas_build_reference_sbvh(const float * positions, int32_t triangle_cou
 /* Appends the box-filter mip chain to level 0 (texels_rgb holds w*h float3 on entry and must have
  * room for w*h + w*h/3 + 1 texels); fills desc like Texture::load.                               */
 int rtxh_texture_mips(float * texels_rgb, int32_t width, int32_t height, rtx_texture_desc * desc, int64_t * texel_count_out);
+
+/* Texture::load (Texture.cpp:30-129): decodes a .png or .tga file the way the reference's vendored stb_image v2.19 does with
+ * STBI_rgb_alpha (Texture.cpp:40), converts r,g,b bytes to linear light (colour_unpack :13-20, Math::gamma_to_linear Math.h:67-77;
+ * alpha is dropped) and, when mipmap_mode != 0 (TEXTURE_SAMPLE_MODE_MIPMAP) and both sides are powers of two, appends the
+ * box-filter chain.  *texels_out is malloc'ed (free with rtxh_texture_free) and holds *texel_count_out float3 texels, ready for
+ * rtx_upload_texture.  Returns RTX_ERR_STATE if the file cannot be read, RTX_ERR_LIMIT for an image format stb_image knows
+ * but this loader does not (JPEG, BMP, GIF, PSD, PIC, PNM, HDR), RTX_ERR_INVALID_ARG for a corrupt file (the reference aborts). */
+int rtxh_texture_load(const char * path, int32_t mipmap_mode, float ** texels_out, int64_t * texel_count_out, rtx_texture_desc * desc);
+int rtxh_texture_free(float * texels);
+/* The decode step alone: width*height RGBA8 pixels, top row first (malloc'ed; free with rtxh_image_free). */
+int rtxh_image_load(const char * path, int32_t * width, int32_t * height, uint8_t ** rgba_out);
+int rtxh_image_free(uint8_t * rgba);
 
 /* Procedural "atrium": returns the triangle count for a detail level, then fills caller arrays.   */
 typedef struct rtxh_mesh {

@@ -1,0 +1,71 @@
+"""texture files -> texels (Texture::load, Texture.cpp:30-129) in librtx_host.so.
+
+Pinned by the reference's own vendored decoder: tests/golden/images/expected.npz holds what stb_image v2.19
+(stbi_load(..., STBI_rgb_alpha), Texture.cpp:40; built from /root/reference/include by oracle/ref_harness) returned for
+each fixture file; oracle/ref_harness/make_image_goldens.py additionally compared all 51 .png/.tga files of the
+reference's Data/ directory (reference_data_check.json).  floor.png and heat_palette.png are data files of the reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import util
+from pyrtx import host, scene_io as sio
+
+D = os.path.join(util.GOLDEN, "images")
+EXPECTED = np.load(os.path.join(D, "expected.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(EXPECTED.files))
+def test_decoder_matches_stb_image(name):
+    got = host.load_image(os.path.join(D, name))
+    assert got.shape == EXPECTED[name].shape
+    assert np.array_equal(got, EXPECTED[name])
+
+
+def test_fixture_set_covers_the_formats():
+    names = set(EXPECTED.files)
+    for color, depths in {0: (1, 2, 4, 8, 16), 2: (8, 16), 3: (1, 2, 4, 8), 4: (8, 16), 6: (8, 16)}.items():
+        for d in depths:
+            assert any(n.startswith(f"png_c{color}_d{d}_adam7") for n in names) and any(n.startswith(f"png_c{color}_d{d}_plain") for n in names)
+    for t, b in [(1, 8), (2, 16), (2, 24), (2, 32), (3, 8), (3, 16)]:
+        assert any(n.startswith(f"tga_t{t}_b{b}") and "_rle" in n for n in names) and any(n.startswith(f"tga_t{t}_b{b}") and "_rle" not in n for n in names)
+    rep = json.load(open(os.path.join(D, "reference_data_check.json")))
+    assert rep["identical"] == 51 and rep["files"] == 52          # the one JPEG (not referenced by any .mtl) is refused, see below
+
+
+def test_texture_load_equals_the_texture_the_reference_sampled():
+    """floor.png through rtxh_texture_load == the texel array dumped from the reference's Texture after Texture::load
+    (golden `dynamic` scene: 32x32, sRGB decode with the host powf, 6 box-filtered levels)."""
+    sc, _ = util.load_golden("dynamic")
+    ref = sc.textures[0]
+    t = host.load_texture(os.path.join(D, "floor.png"))
+    assert t.desc.tobytes() == ref.desc.tobytes()
+    assert t.texels.tobytes() == ref.texels.tobytes()
+    flat = host.load_texture(os.path.join(D, "floor.png"), mipmap_mode=False)          # TEXTURE_SAMPLE_MODE != MIPMAP
+    assert int(flat.desc["mip_levels"][0]) == 1 and int(flat.desc["mipmapped"][0]) == 0
+    assert flat.texels.tobytes() == ref.texels[:32 * 32].tobytes()
+    odd = host.load_texture(os.path.join(D, "heat_palette.png"))                        # 501x1: not a power of two -> no mips
+    assert (int(odd.desc["width"][0]), int(odd.desc["height"][0]), int(odd.desc["mipmapped"][0]), len(odd.texels)) == (501, 1, 0, 501)
+    assert np.array_equal(odd.texels, host.srgb8_to_linear(EXPECTED["heat_palette.png"][0, :, :3]))
+
+
+def test_decoder_errors(tmp_path):
+    def status(data):
+        p = tmp_path / "x.bin"
+        p.write_bytes(data)
+        with pytest.raises(ValueError) as e:
+            host.load_image(str(p))
+        return int(str(e.value).split("status ")[-1])
+    with pytest.raises(ValueError) as e:
+        host.load_image(str(tmp_path / "missing.png"))
+    assert str(e.value).endswith("status 5")                                            # RTX_ERR_STATE: unreadable (the reference aborts)
+    assert status(b"\xff\xd8\xff\xe0" + bytes(64)) == 4                                 # JPEG: known to stb_image, not to this loader
+    assert status(b"BM" + bytes(64)) == 4
+    assert status(bytes([0, 7, 2]) + bytes(64)) == 1                                    # neither PNG nor an acceptable TGA header
+    png = open(os.path.join(D, "png_c2_d8_plain_trns.png"), "rb").read()
+    assert status(png[:len(png) // 2]) == 1                                             # truncated
+    broken = bytearray(png); broken[8 + 8 + 8] = 3                                      # bit depth 3
+    assert status(bytes(broken)) == 1
+    assert status(b"") == 1
