@@ -304,6 +304,7 @@ extern "C" int rtx_set_frame(rtx_ctx * c, const rtx_frame * f) {
     DevScene & s = c->scene;
     s.width = c->cfg.width; s.height = c->cfg.height; s.bounces = c->cfg.bounces; s.stack_size = c->cfg.stack_size;
     s.traversal_strategy = c->cfg.traversal_strategy; s.texture_mode = c->cfg.texture_mode; s.mip_filter = c->cfg.mip_filter;
+    s.heatmap = c->cfg.heatmap ? 1 : 0;
     s.diff_enabled = c->cfg.texture_mode == RTX_TEXTURE_MIPMAP;            // RAY_DIFFERENTIALS_ENABLED, Config.h:46
     s.max_anisotropy = c->cfg.max_anisotropy;
     s.tile_count_x = (c->cfg.width + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE;   // Window.cpp:11
@@ -423,7 +424,7 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
         DevQueues q = c->q;
         q.first_tile = first_tile + done * tile_stride; q.tile_stride = tile_stride; q.tile_count = n; q.primary_slots = n * 1024;
         const DevScene sc = c->scene;
-        const bool plain = count_work || simple;
+        const bool plain = count_work || simple || sc.heatmap;
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, q.counters, (uint32_t)q.primary_slots,
                            (uint32_t)((plain ? c->trace_blocks_count : c->trace_blocks_closest) * RTX_TRACE_BLOCK),
                            (uint32_t)((plain ? c->trace_blocks_count : c->trace_blocks_any) * RTX_TRACE_BLOCK));
@@ -432,6 +433,15 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
         // closest/shade kernels; the shadow rays of levels 1..D are traced by ONE more launch after shade(D).  This removes
         // three of the per-launch tails (a persistent trace launch has a ~0.17 ms floor set by its slowest rays).
         const bool overlap = !count_work && !simple && sc.light_count > 0 && !c->serial;
+        if (sc.heatmap) {
+            // BVH_VISUALIZE_HEATMAP: bounce() returns right after the primary ray's trace (Raytracer.cpp:97-102), so a frame is one
+            // closest-hit pass in reference pop order (the plain kernel counts the steps) and one colouring pass
+            launch_timed(c, "k_trace_closest", c->stream, [&] {
+                if (count_work) hipLaunchKernelGGL((k_trace<false, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, 0);
+                else            hipLaunchKernelGGL((k_trace<false, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, 0); });
+            launch_timed(c, "k_heatmap", c->stream, [&] { hipLaunchKernelGGL(k_heatmap, dim3(stream_blocks), dim3(256), 0, c->stream, sc, q); });
+            continue;
+        }
         for (int level = 0; level < levels; level++) {
             launch_timed(c, "k_trace_closest", c->stream, [&] {
                 if (count_work)   hipLaunchKernelGGL((k_trace<false, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);

@@ -65,6 +65,7 @@ enum { W_CLOSEST_RAYS, W_ANY_RAYS, W_TLAS_C, W_TLAS_A, W_BLAS_C, W_BLAS_A, W_INS
 struct DevScene {
     int32_t width, height, bounces, stack_size;
     int32_t traversal_strategy, texture_mode, mip_filter, diff_enabled;
+    int32_t heatmap;                               // BVH_VISUALIZE_HEATMAP, Config.h:23
     float   max_anisotropy;
     int32_t tile_count_x;
     // camera (Camera.h:10-23)

@@ -423,6 +423,25 @@ RTX_D uint32_t plot_pack(v3 c) {
     return (uint32_t)((r << 16) | (g << 8) | b);
 }
 
+// BVH_VISUALIZE_HEATMAP (Raytracer.cpp:97-102): the pixel is the primary ray's BLAS step count scaled per channel; no shading,
+// no secondary rays.  k_trace<false, *> left the count in h1 (-1 = pixel clipped off the frame).
+__global__ __launch_bounds__(256)
+void k_heatmap(const DevScene sc, const DevQueues q) {
+    uint32_t n_primary = 0;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < (uint32_t)q.primary_slots; slot += gridDim.x * blockDim.x) {
+        int px, py;
+        if (!primary_pixel(sc, q, slot, px, py)) continue;
+        const float steps = (float)q.h1[(uint32_t)q.level_base[0] + slot];
+        const v3 colour = V3(steps * (1.0f / 32.0f), steps * (1.0f / 256.0f), steps * (1.0f / 512.0f));
+        const size_t pixel = (size_t)py * sc.width + px;
+        q.fb_rgb[3 * pixel + 0] = colour.x; q.fb_rgb[3 * pixel + 1] = colour.y; q.fb_rgb[3 * pixel + 2] = colour.z;
+        q.fb_packed[pixel] = plot_pack(colour);
+        n_primary++;
+    }
+    for (int off = 32; off > 0; off >>= 1) n_primary += __shfl_down(n_primary, off);
+    if ((threadIdx.x & 63) == 0 && n_primary) atomicAdd(&q.counters->stats[0], (unsigned long long)n_primary);
+}
+
 __global__ __launch_bounds__(256)
 void k_resolve(const DevScene sc, const DevQueues q, const int level) {
     const DevCounters * const ctr = q.counters;

@@ -144,6 +144,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
     const float4 * cur_nodes = sc.tlas_nodes;
     const float4 * cur_tris  = nullptr;
     uint32_t n_tlas = 0, n_blas = 0, n_inst = 0, n_tri = 0, n_rays = 0, n_stackerr = 0;
+    int bvh_steps = 0;                             // RayHit::bvh_steps (RayHit.h:24-26), kept only for sc.heatmap
 
     auto push = [&](int e) {
         if (sp < RTX_LDS_STACK) stk[sp * RTX_WAVE] = e;
@@ -197,7 +198,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
                         wo = V3(r0.x, r0.y, r0.z); wd = V3(r0.w, r1.x, r1.y);
                     }
                     tcur = INFINITY;
-                    best_prim = PRIM_NONE; best_tri = 0; best_u = 0.0f; best_v = 0.0f;
+                    best_prim = PRIM_NONE; best_tri = 0; best_u = 0.0f; best_v = 0.0f; bvh_steps = 0;
                 }
                 if (live) {
                     if (COUNT) n_rays++;
@@ -243,7 +244,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
             }
             if (sp == 0) {                                  // ray finished
                 if (ANY) q.socc[out_slot] = 0u;
-                else { q.h0[out_slot] = make_float4(tcur, best_u, best_v, as_f(best_prim)); q.h1[out_slot] = best_tri; }
+                else { q.h0[out_slot] = make_float4(tcur, best_u, best_v, as_f(best_prim)); q.h1[out_slot] = sc.heatmap ? bvh_steps : best_tri; }
                 has_ray = false;
                 continue;
             }
@@ -265,6 +266,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
             const float4 na = cur_nodes[2 * e], nb = cur_nodes[2 * e + 1];
             if (COUNT) { if (floor_sp >= 0) n_blas++; else n_tlas++; }
             if (!slab_test(na, nb, co, cinv, tcur)) continue;
+            if (!ANY && floor_sp >= 0) bvh_steps++;         // BottomLevelBVH.cpp:390: BLAS nodes that passed the slab test
             const int first = as_i(na.w), cnt = as_i(nb.w);
             if ((cnt & 0x3fffffff) > 0) {
                 if (floor_sp >= 0) {

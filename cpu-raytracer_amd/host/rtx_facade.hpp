@@ -38,12 +38,13 @@ struct Config {
     int   TEXTURE_SAMPLE_MODE = RTX_TEXTURE_MIPMAP;
     int   MIPMAP_FILTER = RTX_MIP_ANISOTROPIC;
     float MAX_ANISOTROPY = 8.0f;
+    bool  BVH_VISUALIZE_HEATMAP = false;
     int   device = 0;
     rtx_config c_struct() const {
         rtx_config c; std::memset(&c, 0, sizeof(c));
         c.width = SCREEN_WIDTH; c.height = SCREEN_HEIGHT; c.bounces = NUMBER_OF_BOUNCES; c.stack_size = BVH_TRAVERSAL_STACK_SIZE;
         c.traversal_strategy = BVH_TRAVERSAL_STRATEGY; c.texture_mode = TEXTURE_SAMPLE_MODE; c.mip_filter = MIPMAP_FILTER;
-        c.max_anisotropy = MAX_ANISOTROPY; c.device = device;
+        c.max_anisotropy = MAX_ANISOTROPY; c.device = device; c.heatmap = BVH_VISUALIZE_HEATMAP ? 1 : 0;
         return c;
     }
 };

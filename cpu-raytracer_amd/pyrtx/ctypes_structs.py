@@ -13,7 +13,7 @@ RTX_MAX_MIP_LEVELS = 16
 class RtxConfig(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bounces", C.c_int32), ("stack_size", C.c_int32),
                 ("traversal_strategy", C.c_int32), ("texture_mode", C.c_int32), ("mip_filter", C.c_int32),
-                ("max_anisotropy", C.c_float), ("device", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("max_anisotropy", C.c_float), ("device", C.c_int32), ("heatmap", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class RtxTextureDesc(C.Structure):

@@ -331,11 +331,11 @@ def _procedural_textures(seed: int) -> List[sio.Texture]:
     return [texture_with_mips(srgb8_to_linear(img)) for img in procedural_texture_images(seed)]
 
 
-def make_config(width, height, bounces, mip_filter=1, texture_mode=2, stack_size=64, traversal=1, max_aniso=8.0) -> np.ndarray:
+def make_config(width, height, bounces, mip_filter=1, texture_mode=2, stack_size=64, traversal=1, max_aniso=8.0, heatmap=0) -> np.ndarray:
     cfg = np.zeros(1, sio.CONFIG)
     cfg["width"] = width; cfg["height"] = height; cfg["bounces"] = bounces; cfg["stack_size"] = stack_size
     cfg["traversal_strategy"] = traversal; cfg["texture_mode"] = texture_mode; cfg["mip_filter"] = mip_filter
-    cfg["max_anisotropy"] = max_aniso
+    cfg["max_anisotropy"] = max_aniso; cfg["heatmap"] = heatmap
     return cfg
 
 

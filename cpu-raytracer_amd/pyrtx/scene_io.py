@@ -25,7 +25,7 @@ f32, i32, u32, u64 = np.float32, np.int32, np.uint32, np.uint64
 
 CONFIG = np.dtype([("width", i32), ("height", i32), ("bounces", i32), ("stack_size", i32),
                    ("traversal_strategy", i32), ("texture_mode", i32), ("mip_filter", i32),
-                   ("max_anisotropy", f32), ("device", i32), ("reserved", i32, (7,))])
+                   ("max_anisotropy", f32), ("device", i32), ("heatmap", i32), ("reserved", i32, (6,))])
 BVH_NODE = np.dtype([("aabb_min", f32, (3,)), ("aabb_max", f32, (3,)), ("left_or_first", i32), ("count", i32)])
 TRI_HOT = np.dtype([("position_0", f32, (3,)), ("position_edge_1", f32, (3,)), ("position_edge_2", f32, (3,))])
 TRI_COLD = np.dtype([("tex_coord_0", f32, (2,)), ("tex_coord_edge_1", f32, (2,)), ("tex_coord_edge_2", f32, (2,)),

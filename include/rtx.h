@@ -65,7 +65,8 @@ typedef struct rtx_config {
     int32_t mip_filter;          /* MIPMAP_FILTER                                   */
     float   max_anisotropy;      /* MAX_ANISOTROPY                                  */
     int32_t device;              /* HIP device ordinal for this context             */
-    int32_t reserved[7];
+    int32_t heatmap;             /* BVH_VISUALIZE_HEATMAP (Config.h:23): pixels show BLAS traversal steps of the primary ray (Raytracer.cpp:97-102) */
+    int32_t reserved[6];
 } rtx_config;
 
 /* ---- geometry records (reference layouts) ------------------------------ */

@@ -60,8 +60,10 @@ def stage():
 def run_ref(variant, script_path, name):
     exe = os.path.join(REPO, "oracle", "_ref", "refdump_" + variant)
     if not os.path.exists(exe):
-        s, m, b, t = [x[1:] for x in variant.split("_")]
-        subprocess.check_call(["make", "-C", HERE, "variant", f"SCENE={s}", f"MIP={m}", f"BOUNCES={b}", f"TEXMODE={t}"])
+        parts = variant.split("_")
+        s, m, b, t = [x[1:] for x in parts[:4]]
+        subprocess.check_call(["make", "-C", HERE, "variant", f"SCENE={s}", f"MIP={m}", f"BOUNCES={b}", f"TEXMODE={t}",
+                               "ACCEL=" + ("0" if "bvh" in parts[4:] else "1"), "HEAT=" + ("true" if "heat" in parts[4:] else "false")])
     out = os.path.join(WORK, "out_" + name)
     shutil.rmtree(out, ignore_errors=True)
     subprocess.check_call([exe, script_path, out], cwd=WORK, stdout=subprocess.DEVNULL)
@@ -122,12 +124,18 @@ def main():
         print(name, tag or "", variant, "stats", g["stats"].tolist())
         return out
 
+    tp = ["texprobe ./Data/Floor.png 2048 12345", "texprobe ./Data/LEGOSHLD.tga 2048 777"]
+    mat_extra = ["size 320 180", "matset mesh:0:0 texture ./Data/LEGOSHLD.tga"] + tp
+    # BVH_VISUALIZE_HEATMAP builds (Config.h:23, Raytracer.cpp:97-102): same scenes, pixels = BLAS traversal steps
+    golden("monkey_small", "monkey_small", "s0_m1_b3_t2_heat", keep_scene=False, tag="heat")
+    golden("materials", "materials", "s0_m1_b3_t2_heat", extra=mat_extra[:2], keep_scene=False, tag="heat")
+    if "--heat-only" in sys.argv:
+        return
+
     golden("cube", "cube", "s0_m1_b0_t2")
     golden("monkey", "monkey", "s0_m1_b3_t2", sample=8192)
     golden("monkey_small", "monkey_small", "s0_m1_b3_t2")
 
-    tp = ["texprobe ./Data/Floor.png 2048 12345", "texprobe ./Data/LEGOSHLD.tga 2048 777"]
-    mat_extra = ["size 320 180", "matset mesh:0:0 texture ./Data/LEGOSHLD.tga"] + tp
     o_an = golden("materials", "materials", "s0_m1_b3_t2", extra=mat_extra, tag="aniso")
     o_tr = golden("materials", "materials", "s0_m0_b3_t2", extra=mat_extra, tag="trilinear", keep_scene=False)
     o_ew = golden("materials", "materials", "s0_m2_b3_t2", extra=mat_extra, tag="ewa", keep_scene=False)

@@ -302,7 +302,7 @@ int main(int argc, char ** argv) {
 		ChunkWriter cw(outdir + "/scene.rtxs");
 		rtx_config conf; memset(&conf, 0, sizeof(conf));
 		conf.width = W; conf.height = H; conf.bounces = bounces; conf.stack_size = BVH_TRAVERSAL_STACK_SIZE;
-		conf.traversal_strategy = BVH_TRAVERSAL_STRATEGY; conf.texture_mode = TEXTURE_SAMPLE_MODE; conf.mip_filter = MIPMAP_FILTER;
+		conf.traversal_strategy = BVH_TRAVERSAL_STRATEGY; conf.texture_mode = TEXTURE_SAMPLE_MODE; conf.mip_filter = MIPMAP_FILTER; conf.heatmap = BVH_VISUALIZE_HEATMAP ? 1 : 0;
 		conf.max_anisotropy = MAX_ANISOTROPY; conf.device = 0;
 		cw.chunk("CONF", 1, &conf, sizeof(conf));
 

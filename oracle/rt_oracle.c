@@ -78,6 +78,7 @@ typedef struct {          /* RayHit.h:4-36 */
     float u, v;
     float ds_dx, ds_dy, dt_dx, dt_dy;
     v3    dO_dx, dO_dy, dN_dx, dN_dy;
+    int   bvh_steps;      /* RayHit.h:24-26 (BVH_VISUALIZE_HEATMAP) */
 } hit_t;
 
 typedef struct {
@@ -205,10 +206,12 @@ static void blas_trace(const orc_scene * sc, const orc_blas * b, const ray_t * r
     int stack_size = 1;
     stack[0] = 0;
     v3 inv_dir = V3(1.0f / ray->direction.x, 1.0f / ray->direction.y, 1.0f / ray->direction.z);
+    int steps = 0;                                          /* :362,390: nodes that passed the slab test */
     while (stack_size > 0) {
         const rtx_bvh_node * node = &b->nodes[stack[--stack_size]];
         c->work.blas_nodes_closest++;
         if (!aabb_intersect(node, ray->origin, inv_dir, h->distance)) continue;
+        steps++;
         if (((uint32_t)node->count & ~AXIS_MASK) > 0) {
             for (int i = node->left_or_first; i < node->left_or_first + node->count; i++) {
                 c->work.tri_tests_closest++;
@@ -224,6 +227,7 @@ static void blas_trace(const orc_scene * sc, const orc_blas * b, const ray_t * r
             }
         }
     }
+    h->bvh_steps += steps;                                  /* :393-395 */
 }
 
 /* BottomLevelBVH::intersect, BottomLevelBVH.cpp:398-437 */
@@ -687,6 +691,11 @@ static v3 bounce(const orc_scene * sc, const ray_t * ray, int bounces_left, floa
     h.hit = 0;
     h.distance = INFINITY;
     scene_trace(sc, ray, &h, c);
+
+    if (sc->config.heatmap) {                               /* BVH_VISUALIZE_HEATMAP, :97-102 (the out distance stays unset there; INFINITY here) */
+        *distance = INFINITY;
+        return V3(h.bvh_steps * (1.0f / 32.0f), h.bvh_steps * (1.0f / 256.0f), h.bvh_steps * (1.0f / 512.0f));
+    }
 
     if (!h.hit) {                                           /* :105-111 */
         c->work.sky_lookups++;

@@ -158,3 +158,22 @@ def test_bench_gather_path_on_one_gpu():
     j = json.loads(out.stdout.strip().splitlines()[-1])
     assert j["gathered_frame_equals_single_gpu_frame"] is True
     assert j["rays_per_frame"]["total"] == 57600 + 191709 + 52955 + 12692
+
+
+@pytest.mark.parametrize("name", ["monkey_small_heat", "materials_heat"])
+def test_heatmap_mode_is_bit_exact(api, name):
+    """BVH_VISUALIZE_HEATMAP: integer step counts times powers of two, so the frame must equal the reference's bit for bit;
+    only primary rays are counted; rendering the odd and even tiles separately composes the same frame."""
+    sc, g = util.load_golden(name)
+    r = api.Renderer(sc)
+    out = r.render()
+    cmp = util.compare_to_golden(out, g)
+    assert cmp["bit_exact"] and cmp["packed_mismatch"] == 0 and cmp["stats_equal"], cmp
+    assert out["stats"]["shadow"] == 0 and out["stats"]["reflection"] == 0 and out["stats"]["refraction"] == 0
+    counted = r.render(count_work=True)
+    assert np.array_equal(counted["rgb"], out["rgb"]) and counted["work"]["closest_rays"] == sc.width * sc.height
+    r2 = api.Renderer(sc)
+    T = sc.tile_count
+    r2.render(first_tile=0, tile_stride=2, tile_count=(T + 1) // 2)
+    half = r2.render(first_tile=1, tile_stride=2, tile_count=T // 2)
+    assert np.array_equal(half["packed"], out["packed"])

@@ -18,6 +18,9 @@ GOLDENS = {
     "materials_trilinear": ("materials", "trilinear", {"mip_filter": 0, "texture_mode": 2}),
     "materials_ewa": ("materials", "ewa", {"mip_filter": 2, "texture_mode": 2}),
     "materials_bilinear": ("materials", "bilinear", {"mip_filter": 1, "texture_mode": 1}),
+    # BVH_VISUALIZE_HEATMAP builds of the reference (Config.h:23, Raytracer.cpp:97-102) on the same two scenes
+    "monkey_small_heat": ("monkey_small", "heat", {"heatmap": 1}),
+    "materials_heat": ("materials", "heat", {"heatmap": 1, "mip_filter": 1, "texture_mode": 2}),
     "dynamic": ("dynamic", None, {}),
     "tori16": ("tori16", None, {}),
     "tori16_f1": ("tori16_f1", None, {}),
