@@ -128,7 +128,8 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RTX_ERR_HIP; }
     c->stream = c->own_stream;
-    if (hipStreamCreateWithFlags(&c->any_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RTX_ERR_HIP; }
+    // any_stream is created on first use (two-stream mode only): HIP multiplexes streams onto a few hardware queues, and an unused
+    // stream per context would push other contexts' streams onto shared queues
     hipEventCreateWithFlags(&c->ev_shade0, hipEventDisableTiming); hipEventCreateWithFlags(&c->ev_shade_last, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_any_done, hipEventDisableTiming);
 
@@ -167,7 +168,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     int max_blocks = c->trace_blocks_closest > c->trace_blocks_any ? c->trace_blocks_closest : c->trace_blocks_any;
     if (c->trace_blocks_count > max_blocks) max_blocks = c->trace_blocks_count;
     c->q.spill_threads = max_blocks * RTX_TRACE_BLOCK;
-    rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4);
+    rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast
     if (rc) { rtx_destroy(c); return rc; }
     *out_ctx = c;
     return RTX_OK;
@@ -433,6 +434,7 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
         // closest/shade kernels; the shadow rays of levels 1..D are traced by ONE more launch after shade(D).  This removes
         // three of the per-launch tails (a persistent trace launch has a ~0.17 ms floor set by its slowest rays).
         const bool overlap = !count_work && !simple && sc.light_count > 0 && !c->serial;
+        if (overlap && !c->any_stream) HIP_OK(c, hipStreamCreateWithFlags(&c->any_stream, hipStreamNonBlocking));
         if (sc.heatmap) {
             // BVH_VISUALIZE_HEATMAP: bounce() returns right after the primary ray's trace (Raytracer.cpp:97-102), so a frame is one
             // closest-hit pass in reference pop order (the plain kernel counts the steps) and one colouring pass

@@ -119,7 +119,7 @@ struct DevQueues {
     float4 *   sc; // unshadowed light contribution.xyz, -
     uint32_t * socc; // 1 = occluded
 
-    int32_t *     spill;          // traversal stack spill: [(entry - RTX_LDS_STACK) * spill_threads + thread]
+    int32_t *     spill;          // traversal stack spill, 3 regions of [(entry - RTX_LDS_STACK) * spill_threads + thread]: closest entries, closest keys, shadow entries
     int32_t       spill_threads;
     DevCounters * counters;
     float *       fb_rgb;         // W*H*3

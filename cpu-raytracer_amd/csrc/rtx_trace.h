@@ -37,6 +37,19 @@
 #endif
 #define RAY_EPSILON      0.005f // Ray.h:5
 
+// Per-lane pointers to BVH nodes / triangles come out of device tables (DevBlas), so the compiler cannot prove their address
+// space and would emit FLAT loads (LDS-aperture check, lgkmcnt + vmcnt).  They always point into HBM: say so.
+#ifndef RTX_NANFREE_ANY
+#define RTX_NANFREE_ANY 1        // use the NaN-free slab test in waves without +-0 direction components (shadow-ray kernel)
+#endif
+#ifndef RTX_NANFREE_CLOSEST
+#define RTX_NANFREE_CLOSEST 0    // same for the closest-hit kernel (costs it registers: 119 -> 139 VGPRs, one wave per SIMD less)
+#endif
+typedef float rtx_f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) rtx_f4v * rtx_gptr;
+#define RTX_GPTR(p) ((rtx_gptr)(const void *)(p))
+RTX_D float4 gld(rtx_gptr p, int i) { const rtx_f4v v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+
 // Slot -> pixel of a primary ray.  1024 slots per tile, a wave covers an 8x8 pixel block.
 RTX_D bool primary_pixel(const DevScene & sc, const DevQueues & q, uint32_t slot, int & px, int & py) {
     int tile_k = slot >> 10, l = slot & 1023;
@@ -80,6 +93,41 @@ RTX_D bool slab_test(float4 a, float4 b, v3 o, v3 inv, float max_distance) {
     float t_near = fmax_ref(fmax_ref(RAY_EPSILON, tmin.x), fmax_ref(tmin.y, tmin.z));
     float t_far  = fmin_ref(fmin_ref(max_distance, tmax.x), fmin_ref(tmax.y, tmax.z));
     return t_near < t_far;
+}
+
+// The same test, also returning the key that decides the reference's POP-time re-test of this node.  With min(a,b) = a<b?a:b,
+// t_far(D) = min(min(D, X), M), X = tmax.x, M = min(tmax.y, tmax.z).  If the node passes for some D, then for any later D' <= D:
+//   X is NaN (0 * inf on the x slab): min(D, NaN) = NaN and min(NaN, M) = M, so t_far does not depend on D -> it passes again;
+//   otherwise t_near < X and t_near < M are already known, so pass(D') == (t_near < D').
+// key = -inf in the first case, t_near in the second: the pop-time test is exactly `key < D'`, with no memory access.
+RTX_D bool slab_test_key(float4 a, float4 b, v3 o, v3 inv, float max_distance, float & key) {
+    v3 t0 = vmul(vsub(V3(a.x, a.y, a.z), o), inv);
+    v3 t1 = vmul(vsub(V3(b.x, b.y, b.z), o), inv);
+    v3 tmin = V3(fmin_ref(t0.x, t1.x), fmin_ref(t0.y, t1.y), fmin_ref(t0.z, t1.z));
+    v3 tmax = V3(fmax_ref(t0.x, t1.x), fmax_ref(t0.y, t1.y), fmax_ref(t0.z, t1.z));
+    float t_near = fmax_ref(fmax_ref(RAY_EPSILON, tmin.x), fmax_ref(tmin.y, tmin.z));
+    float t_far  = fmin_ref(fmin_ref(max_distance, tmax.x), fmin_ref(tmax.y, tmax.z));
+    key = (tmax.x != tmax.x) ? -INFINITY : t_near;
+    return t_near < t_far;
+}
+
+// NaN-free variant.  The only NaN a slab test can produce is 0 * inf: a box plane through the ray origin on an axis whose
+// direction component is +-0 (inverse +-inf).  When all three inverse components are FINITE every t0 / t1 is finite or +-inf,
+// and on non-NaN operands `a < b ? a : b` and the hardware v_min_f32 / v_max_f32 / v_min3 / v_max3 agree (up to the sign of a
+// zero, which no comparison below can see: t_near >= EPSILON > 0).  Half the VALU instructions of the reference-form test.
+// FAST must only be true when inv.x, inv.y, inv.z are all finite (the kernels check per wave).
+template <bool FAST>
+RTX_D bool slab_test_sel(float4 a, float4 b, v3 o, v3 inv, float max_distance, float & key) {
+    if (!FAST) return slab_test_key(a, b, o, inv, max_distance, key);
+    v3 t0 = vmul(vsub(V3(a.x, a.y, a.z), o), inv);
+    v3 t1 = vmul(vsub(V3(b.x, b.y, b.z), o), inv);
+    const float t_near = __builtin_fmaxf(__builtin_fmaxf(RAY_EPSILON, __builtin_fminf(t0.x, t1.x)), __builtin_fmaxf(__builtin_fminf(t0.y, t1.y), __builtin_fminf(t0.z, t1.z)));
+    const float t_far  = __builtin_fminf(__builtin_fminf(max_distance, __builtin_fmaxf(t0.x, t1.x)), __builtin_fminf(__builtin_fmaxf(t0.y, t1.y), __builtin_fmaxf(t0.z, t1.z)));
+    key = t_near;
+    return t_near < t_far;
+}
+RTX_D bool inv_is_finite(v3 inv) {
+    return (__builtin_fabsf(inv.x) < INFINITY) & (__builtin_fabsf(inv.y) < INFINITY) & (__builtin_fabsf(inv.z) < INFINITY);   // false for inf and NaN
 }
 
 // Sphere::trace hit test only (Sphere.cpp:9-42); attributes are rebuilt in the shade kernel
@@ -141,8 +189,8 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
     float tcur = 0.0f;                             // closest t so far (ANY: max distance)
     int best_prim = PRIM_NONE, best_tri = 0; float best_u = 0.0f, best_v = 0.0f;
     int sp = 0, floor_sp = -1, cur_inst = 0;
-    const float4 * cur_nodes = sc.tlas_nodes;
-    const float4 * cur_tris  = nullptr;
+    rtx_gptr cur_nodes = RTX_GPTR(sc.tlas_nodes);
+    rtx_gptr cur_tris  = nullptr;
     uint32_t n_tlas = 0, n_blas = 0, n_inst = 0, n_tri = 0, n_rays = 0, n_stackerr = 0;
     int bvh_steps = 0;                             // RayHit::bvh_steps (RayHit.h:24-26), kept only for sc.heatmap
 
@@ -218,7 +266,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
                     } else if (sc.tlas_node_count > 0) {
                         winv = vrcp(wd);
                         co = wo; cd = wd; cinv = winv;
-                        cur_nodes = sc.tlas_nodes; floor_sp = -1;
+                        cur_nodes = RTX_GPTR(sc.tlas_nodes); floor_sp = -1;
                         sp = 0; push(0);
                         has_ray = true;
                     } else {
@@ -240,7 +288,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
         for (int it = 0; it < RTX_TRACE_STEPS; it++) {
             if (!has_ray) continue;
             if (floor_sp >= 0 && sp == floor_sp) {          // BottomLevelBVH::trace returned: back to world space
-                floor_sp = -1; co = wo; cd = wd; cinv = winv; cur_nodes = sc.tlas_nodes;
+                floor_sp = -1; co = wo; cd = wd; cinv = winv; cur_nodes = RTX_GPTR(sc.tlas_nodes);
             }
             if (sp == 0) {                                  // ray finished
                 if (ANY) q.socc[out_slot] = 0u;
@@ -257,13 +305,13 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
                 cd = xform_dir(I.world_inv, wd);
                 cinv = vrcp(cd);
                 const DevBlas & B = sc.blas[I.blas_id];
-                cur_nodes = B.nodes; cur_tris = B.tri_hot; cur_inst = inst;
+                cur_nodes = RTX_GPTR(B.nodes); cur_tris = RTX_GPTR(B.tri_hot); cur_inst = inst;
                 floor_sp = sp;
                 push(0);
                 if (COUNT) n_inst++;
                 continue;
             }
-            const float4 na = cur_nodes[2 * e], nb = cur_nodes[2 * e + 1];
+            const float4 na = gld(cur_nodes, 2 * e), nb = gld(cur_nodes, 2 * e + 1);
             if (COUNT) { if (floor_sp >= 0) n_blas++; else n_tlas++; }
             if (!slab_test(na, nb, co, cinv, tcur)) continue;
             if (!ANY && floor_sp >= 0) bvh_steps++;         // BottomLevelBVH.cpp:390: BLAS nodes that passed the slab test
@@ -273,7 +321,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
                     // BLAS leaf: triangle_trace / triangle_intersect (BottomLevelBVH.cpp:214-346)
                     for (int i = first; i < first + cnt; i++) {
                         if (COUNT) n_tri++;
-                        const float4 p0 = cur_tris[3 * i], e1 = cur_tris[3 * i + 1], e2 = cur_tris[3 * i + 2];
+                        const float4 p0 = gld(cur_tris, 3 * i), e1 = gld(cur_tris, 3 * i + 1), e2 = gld(cur_tris, 3 * i + 2);
                         const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
                         const v3 h = vcross(cd, edge_2);
                         const float a = vdot(edge_1, h);
@@ -346,12 +394,19 @@ template <bool ANY>
 __global__ __launch_bounds__(RTX_TRACE_BLOCK, ANY ? RTX_WAVES_ANY : RTX_WAVES_CLOSEST)
 void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const int level_hi) {
     __shared__ int lds_stack[RTX_TRACE_BLOCK / RTX_WAVE][RTX_LDS_STACK][RTX_WAVE];
+    // closest-hit rays carry a second word per entry: the pop-time key of slab_test_key (shadow rays never re-test)
+    __shared__ float lds_key[ANY ? 1 : RTX_TRACE_BLOCK / RTX_WAVE][ANY ? 1 : RTX_LDS_STACK][RTX_WAVE];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     int * const stk = &lds_stack[wave][0][lane];
+    float * const stk_key = &lds_key[ANY ? 0 : wave][0][lane];
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    int * const spill = q.spill + gtid;
+    // spill regions (ints): [0, S) entries of closest-hit kernels, [S, 2S) their keys, [2S, 3S) shadow-ray kernels, S = threads * depth:
+    // a closest-hit and a shadow-ray launch may be resident together (two streams), so they must not share a region
     const int spill_stride = q.spill_threads;
+    const size_t spill_region = (size_t)spill_stride * (RTX_MAX_STACK - RTX_LDS_STACK);
+    int * const spill = q.spill + (ANY ? 2 * spill_region : 0) + gtid;
+    float * const spill_key = (float *)(q.spill + spill_region) + gtid;
 
     DevCounters * const ctr = q.counters;
     // shadow rays: one launch may cover the levels [level, level_hi]; closest-hit rays: exactly one level
@@ -361,26 +416,28 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
     uint32_t * const head = ANY ? &ctr->fetch_any[level] : &ctr->fetch_closest[level];
     const bool ordered = sc.traversal_strategy == RTX_TRAVERSE_ORDERED;
 
-    bool has_ray = false, have_cur = false;
+    bool has_ray = false, have_cur = false, lane_risky = false;   // lane_risky: cinv has an infinite / NaN component
     uint32_t out_slot = 0;
     v3 wo = V3(0, 0, 0), wd = wo, winv = wo, co = wo, cd = wo, cinv = wo;
     float tcur = 0.0f;
     int best_prim = PRIM_NONE, best_tri = 0; float best_u = 0.0f, best_v = 0.0f;
     int sp = 0, floor_sp = -1, cur_inst = 0;
     int cur_first = 0, cur_cnt = 0;                 // the node being visited: it has already passed its slab test
-    const float4 * cur_nodes = sc.tlas_nodes;
-    const float4 * cur_tris  = nullptr;
+    rtx_gptr cur_nodes = RTX_GPTR(sc.tlas_nodes);
+    rtx_gptr cur_tris  = nullptr;
     uint32_t n_stackerr = 0;
 
-    auto push = [&](int e) {
-        if (sp < RTX_LDS_STACK) stk[sp * RTX_WAVE] = e;
-        else if (sp < RTX_MAX_STACK) spill[(sp - RTX_LDS_STACK) * spill_stride] = e;
+    auto push = [&](int e, float key) {
+        if (sp < RTX_LDS_STACK) { stk[sp * RTX_WAVE] = e; if (!ANY) stk_key[sp * RTX_WAVE] = key; }
+        else if (sp < RTX_MAX_STACK) { spill[(sp - RTX_LDS_STACK) * spill_stride] = e; if (!ANY) spill_key[(sp - RTX_LDS_STACK) * spill_stride] = key; }
         else { n_stackerr = 1; return; }
         sp++;
     };
-    auto pop = [&]() -> int {
+    auto pop = [&](float & key) -> int {
         sp--;
-        return (sp < RTX_LDS_STACK) ? stk[sp * RTX_WAVE] : spill[(sp - RTX_LDS_STACK) * spill_stride];
+        if (sp < RTX_LDS_STACK) { if (!ANY) key = stk_key[sp * RTX_WAVE]; return stk[sp * RTX_WAVE]; }
+        if (!ANY) key = spill_key[(sp - RTX_LDS_STACK) * spill_stride];
+        return spill[(sp - RTX_LDS_STACK) * spill_stride];
     };
     auto finish = [&]() {
         if (ANY) q.socc[out_slot] = 0u;
@@ -449,11 +506,11 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
                         q.socc[out_slot] = 1u;
                     } else if (sc.tlas_node_count > 0) {
                         winv = vrcp(wd);
-                        co = wo; cd = wd; cinv = winv;
-                        cur_nodes = sc.tlas_nodes; floor_sp = -1; sp = 0;
+                        co = wo; cd = wd; cinv = winv; lane_risky = !inv_is_finite(cinv);
+                        cur_nodes = RTX_GPTR(sc.tlas_nodes); floor_sp = -1; sp = 0;
                         has_ray = true;
                         // TLAS root: pushed, popped and tested by the reference (TopLevelBVH.cpp:58-67)
-                        const float4 na = cur_nodes[0], nb = cur_nodes[1];
+                        const float4 na = gld(cur_nodes, 0), nb = gld(cur_nodes, 1);
                         if (slab_test(na, nb, co, cinv, tcur)) { cur_first = as_i(na.w); cur_cnt = as_i(nb.w); have_cur = true; }
                         else finish();
                     } else {
@@ -472,6 +529,8 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
         }
 
         for (int it = 0; it < RTX_TRACE_STEPS; it++) {
+            // all live rays of the wave free of +-0 direction components in the space they are traversing?  (lane_risky follows cinv)
+            const bool wave_nan_free = __ballot(has_ray && lane_risky) == 0ull;
             // ---- A: inner node: fetch the child pair, test both, descend into the near one ----
             // (repeated while most lanes are still walking inner nodes: lanes that reached a leaf or ran dry wait a little,
             //  which keeps the wave converged on the dominant step)
@@ -480,9 +539,11 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
             if (rep > 0 && __popcll(__ballot(has_ray && have_cur && (cur_cnt & 0x3fffffff) == 0)) < RTX_INNER_MIN_LANES) break;
             if (has_ray && have_cur && (cur_cnt & 0x3fffffff) == 0) {
                 const int left = cur_first;
-                const float4 la = cur_nodes[2 * left], lb = cur_nodes[2 * left + 1], ra = cur_nodes[2 * left + 2], rb = cur_nodes[2 * left + 3];
-                const bool pl = slab_test(la, lb, co, cinv, tcur);
-                const bool pr = slab_test(ra, rb, co, cinv, tcur);
+                const float4 la = gld(cur_nodes, 2 * left), lb = gld(cur_nodes, 2 * left + 1), ra = gld(cur_nodes, 2 * left + 2), rb = gld(cur_nodes, 2 * left + 3);
+                float kl = 0.0f, kr = 0.0f;
+                bool pl, pr;
+                if ((ANY ? RTX_NANFREE_ANY : RTX_NANFREE_CLOSEST) && wave_nan_free) { pl = slab_test_sel<true>(la, lb, co, cinv, tcur, kl);  pr = slab_test_sel<true>(ra, rb, co, cinv, tcur, kr); }
+                else               { pl = slab_test_sel<false>(la, lb, co, cinv, tcur, kl); pr = slab_test_sel<false>(ra, rb, co, cinv, tcur, kr); }
                 bool left_first = true;                                  // BVHNode::should_visit_left_first, BVHNode.h:30-40
                 if (ordered) {
                     const int axis = (int)((uint32_t)cur_cnt >> 30);
@@ -495,12 +556,13 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
                 const int far_first  = left_first ? as_i(ra.w) : as_i(la.w), far_cnt  = left_first ? as_i(rb.w) : as_i(lb.w);
                 if (p_near) {
                     if (p_far) {
-                        // shadow rays never re-test a far child (their max distance is constant), so its (first, count)
-                        // travel on the stack and the pop needs no memory access; closest-hit rays push the node index
+                        // the far child's (first, count) travel on the stack, so the pop needs no memory access: shadow rays never
+                        // re-test it (their max distance is constant); closest-hit rays re-test it with its key (slab_test_key)
                         const int far_leaf = far_cnt & 0x3fffffff;
-                        if (ANY && (uint32_t)far_first < (1u << 24) && far_leaf < 16)
-                            push((int)(0x40000000u | (((uint32_t)far_cnt >> 30) << 28) | ((uint32_t)far_leaf << 24) | (uint32_t)far_first));
-                        else push(left_first ? left + 1 : left);
+                        const float far_key = left_first ? kr : kl;
+                        if ((uint32_t)far_first < (1u << 24) && far_leaf < 16)
+                            push((int)(0x40000000u | (((uint32_t)far_cnt >> 30) << 28) | ((uint32_t)far_leaf << 24) | (uint32_t)far_first), far_key);
+                        else push(left_first ? left + 1 : left, far_key);
                     }
                     cur_first = near_first; cur_cnt = near_cnt;
                 } else if (p_far) {
@@ -514,7 +576,7 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
                 const int first = cur_first, cnt = cur_cnt;
                 if (floor_sp >= 0) {
                     for (int i = first; i < first + cnt; i++) {
-                        const float4 p0 = cur_tris[3 * i], e1 = cur_tris[3 * i + 1], e2 = cur_tris[3 * i + 2];
+                        const float4 p0 = gld(cur_tris, 3 * i), e1 = gld(cur_tris, 3 * i + 1), e2 = gld(cur_tris, 3 * i + 2);
                         const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
                         const v3 h = vcross(cd, edge_2);
                         const float a = vdot(edge_1, h);
@@ -531,33 +593,36 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
                         tcur = t; best_u = u; best_v = v; best_tri = i; best_prim = PRIM_TRI | cur_inst;
                     }
                 } else {
-                    for (int i = first + cnt - 1; i >= first; i--) push(~i);
+                    for (int i = first + cnt - 1; i >= first; i--) push(~i, 0.0f);
                 }
             }
             // ---- C: pop ----
             if (has_ray && !have_cur) {
-                if (floor_sp >= 0 && sp == floor_sp) { floor_sp = -1; co = wo; cd = wd; cinv = winv; cur_nodes = sc.tlas_nodes; }
+                if (floor_sp >= 0 && sp == floor_sp) { floor_sp = -1; co = wo; cd = wd; cinv = winv; cur_nodes = RTX_GPTR(sc.tlas_nodes); lane_risky = !inv_is_finite(cinv); }
                 if (sp == 0) { finish(); continue; }
-                const int e = pop();
+                float key = 0.0f;
+                const int e = pop(key);
                 if (e < 0) {
                     const int inst = sc.tlas_indices[~e];                // Mesh::trace / intersect, Mesh.cpp:17-40
                     const rtx_instance & I = sc.instances[inst];
                     co = xform_pos(I.world_inv, wo);
                     cd = xform_dir(I.world_inv, wd);
-                    cinv = vrcp(cd);
+                    cinv = vrcp(cd); lane_risky = !inv_is_finite(cinv);
                     const DevBlas & B = sc.blas[I.blas_id];
-                    cur_nodes = B.nodes; cur_tris = B.tri_hot; cur_inst = inst;
+                    cur_nodes = RTX_GPTR(B.nodes); cur_tris = RTX_GPTR(B.tri_hot); cur_inst = inst;
                     floor_sp = sp;
-                    const float4 na = cur_nodes[0], nb = cur_nodes[1];    // BLAS root
+                    const float4 na = gld(cur_nodes, 0), nb = gld(cur_nodes, 1);    // BLAS root
                     if (slab_test(na, nb, co, cinv, tcur)) { cur_first = as_i(na.w); cur_cnt = as_i(nb.w); have_cur = true; }
-                } else if (ANY && (e & 0x40000000)) {
-                    cur_first = e & 0x00ffffff;
-                    cur_cnt = (int)((((uint32_t)e >> 28) & 3u) << 30) | ((e >> 24) & 15);
+                } else if (ANY || key < tcur) {
+                    // far child: the reference tests it now, against the current closest distance == `key < tcur` (slab_test_key)
+                    if (e & 0x40000000) {
+                        cur_first = e & 0x00ffffff;
+                        cur_cnt = (int)((((uint32_t)e >> 28) & 3u) << 30) | ((e >> 24) & 15);
+                    } else {
+                        const float4 na = gld(cur_nodes, 2 * e), nb = gld(cur_nodes, 2 * e + 1);   // too big to pack: read (first, count) back
+                        cur_first = as_i(na.w); cur_cnt = as_i(nb.w);
+                    }
                     have_cur = true;
-                } else {
-                    // far child: the reference tests it now, against the current closest distance
-                    const float4 na = cur_nodes[2 * e], nb = cur_nodes[2 * e + 1];
-                    if (ANY || slab_test(na, nb, co, cinv, tcur)) { cur_first = as_i(na.w); cur_cnt = as_i(nb.w); have_cur = true; }
                 }
             }
         }
