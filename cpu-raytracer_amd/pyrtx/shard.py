@@ -50,10 +50,14 @@ class TileGather:
         self.my_idx = torch.from_numpy(np.where(mine >= 0, mine, 0)).to(device)
         self.send = torch.zeros(len(mine), dtype=torch.int32, device=device)
         if rank == 0:
-            self.recv = [torch.zeros_like(self.send) for _ in range(world)]
+            # one contiguous receive buffer (rank r's tiles at [r*n, (r+1)*n)) and ONE scatter into raster order per frame
+            n = len(mine)
+            self.recv_buf = torch.zeros(world * n, dtype=torch.int32, device=device)
+            self.recv = [self.recv_buf[r * n:(r + 1) * n] for r in range(world)]
             allidx = [tile_pixel_indices(width, height, r, world) for r in range(world)]
-            self.valid = [torch.from_numpy(np.nonzero(a >= 0)[0]).to(device) for a in allidx]
-            self.dest = [torch.from_numpy(a[a >= 0]).to(device) for a in allidx]
+            self.valid = torch.from_numpy(np.concatenate([np.nonzero(a >= 0)[0] + r * n for r, a in enumerate(allidx)])).to(device)
+            self.dest = torch.from_numpy(np.concatenate([a[a >= 0] for a in allidx])).to(device)
+            self.all_valid = int(self.valid.numel()) == world * n
             self.final = torch.zeros(width * height, dtype=torch.int32, device=device)
 
     def __call__(self, packed_flat):
@@ -63,7 +67,7 @@ class TileGather:
         torch.index_select(packed_flat, 0, self.my_idx, out=self.send)
         dist.gather(self.send, self.recv if self.rank == 0 else None, dst=0)
         if self.rank == 0:
-            for r in range(self.world):
-                self.final.index_copy_(0, self.dest[r], self.recv[r].index_select(0, self.valid[r]))
+            src = self.recv_buf if self.all_valid else self.recv_buf.index_select(0, self.valid)
+            self.final.index_copy_(0, self.dest, src)
             return self.final
         return None
