@@ -154,6 +154,61 @@ extern "C" int rtxh_quaternion_axis_angle(const float axis[3], float angle, floa
     return RTX_OK;
 }
 
+// ---- Scene::update, Scene.cpp:139-171 ---------------------------------------------------------------------------------
+namespace {
+struct Q { float x, y, z, w; };
+inline Q q_axis_angle(float ax, float ay, float az, float angle) {                 // Quaternion.h:26-36
+    float half_angle = 0.5f * angle, sine = sinf(half_angle);
+    return Q{ ax * sine, ay * sine, az * sine, cosf(half_angle) };
+}
+inline Q q_mul(Q l, Q r) {                                                          // operator*(Quaternion, Quaternion&), Quaternion.h:118-125
+    return Q{ l.x * r.w + l.w * r.x + l.y * r.z - l.z * r.y,
+              l.y * r.w + l.w * r.y + l.z * r.x - l.x * r.z,
+              l.z * r.w + l.w * r.z + l.x * r.y - l.y * r.x,
+              l.w * r.w - l.x * r.x - l.y * r.y - l.z * r.z };
+}
+inline Q q_nlerp(Q a, Q b, float t) {                                               // Quaternion::nlerp + normalize
+    float one_minus_t = 1.0f - t;
+    Q q{ one_minus_t * a.x + t * b.x, one_minus_t * a.y + t * b.y, one_minus_t * a.z + t * b.z, one_minus_t * a.w + t * b.w };
+    float inv_length = 1.0f / sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    return Q{ q.x * inv_length, q.y * inv_length, q.z * inv_length, q.w * inv_length };
+}
+}  // namespace
+
+// The animation SCENE_DYNAMIC hard-codes into Scene::update (Scene.cpp:141-155): instances 0..5 move, *time accumulates delta.
+extern "C" int rtxh_scene_dynamic_animate(float delta, float * time, float * positions, float * rotations, int32_t instance_count) {
+    if (!time || !positions || !rotations || instance_count < 6) return RTX_ERR_INVALID_ARG;
+    auto rot = [&](int i) -> Q & { return *reinterpret_cast<Q *>(rotations + 4 * i); };
+    float * p = positions;
+    rot(0) = q_mul(q_axis_angle(0.0f, 1.0f, 0.0f, delta), rot(0));
+    *time += delta;
+    const float t = *time;
+    p[3 * 1 + 1] = 1.0f + 2.0f * sinf(t);
+    p[3 * 2 + 0] -= delta * 0.5f;
+    p[3 * 3 + 0] = 6.0f; p[3 * 3 + 1] = 4.0f + 2.0f * sinf(t * 0.5f); p[3 * 3 + 2] = 4.0f + 2.0f * cosf(t * 0.5f);
+    rot(3) = q_mul(q_axis_angle(0.0f, 1.0f, 0.0f, delta * 0.5f), rot(3));
+    rot(4) = q_mul(q_axis_angle(1.0f, 0.0f, 0.0f, delta), rot(4));
+    rot(5) = q_nlerp(Q{ 0.0f, 0.0f, 0.0f, 1.0f }, q_axis_angle(1.0f, 0.0f, 0.0f, (-90.0f) * 3.14159265359f * 0.00555555555f), 0.5f + 0.5f * sinf(t));
+    return RTX_OK;
+}
+
+// Mesh::update for every instance + TopLevelBVH::build_bvh in one call (the tail of Scene::update, Scene.cpp:166-170).
+extern "C" int rtxh_scene_update(rtxh_tlas * tlas, int32_t instance_count, const float * positions, const float * rotations, const int32_t * blas_ids,
+                                 const float * blas_root_aabbs, rtx_instance * instances_out, rtx_bvh_node * tlas_nodes_out,
+                                 int32_t * tlas_indices_out, int32_t * tlas_node_count_out) {
+    if (!tlas || instance_count <= 0 || !positions || !rotations || !blas_ids || !blas_root_aabbs || !instances_out || !tlas_nodes_out || !tlas_indices_out || !tlas_node_count_out)
+        return RTX_ERR_INVALID_ARG;
+    std::vector<float> aabbs(6 * (size_t)instance_count);
+    for (int i = 0; i < instance_count; i++) {
+        memset(&instances_out[i], 0, sizeof(rtx_instance));
+        instances_out[i].blas_id = blas_ids[i];
+        const float * box = blas_root_aabbs + 6 * (size_t)blas_ids[i];
+        int rc = rtxh_instance_update(positions + 3 * i, rotations + 4 * i, box, box + 3, &instances_out[i], &aabbs[6 * (size_t)i], &aabbs[6 * (size_t)i + 3]);
+        if (rc) return rc;
+    }
+    return rtxh_tlas_build(tlas, positions, aabbs.data(), tlas_nodes_out, tlas_indices_out, tlas_node_count_out);
+}
+
 extern "C" int rtxh_plane_update(const float position[3], const float rotation[4], int32_t material_id, rtx_plane * out) {
     if (!position || !rotation || !out) return RTX_ERR_INVALID_ARG;
     float w[16];

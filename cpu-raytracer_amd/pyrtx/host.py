@@ -18,7 +18,7 @@ from .ctypes_structs import RtxCamera, RtxTextureDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "host", "librtx_host.so")
-EXPORTS = ["rtxh_camera_basis", "rtxh_quaternion_axis_angle", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
+EXPORTS = ["rtxh_camera_basis", "rtxh_quaternion_axis_angle", "rtxh_scene_dynamic_animate", "rtxh_scene_update", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
            "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_blas_build_reference_sbvh", "rtxh_texture_mips", "rtxh_texture_load", "rtxh_texture_free", "rtxh_image_load", "rtxh_image_free", "rtxh_atrium_generate", "rtxh_mesh_free",
            "rtxh_obj_load", "rtxh_obj_free"]
 
@@ -55,6 +55,8 @@ def lib():
         l.rtxh_blas_build.argtypes = [vp, i32, i32, vp, C.POINTER(i32), vp]
         l.rtxh_blas_build_reference_bvh.argtypes = [vp, i32, vp, C.POINTER(i32), vp]
         l.rtxh_quaternion_axis_angle.argtypes = [vp, C.c_float, vp]
+        l.rtxh_scene_dynamic_animate.argtypes = [C.c_float, C.POINTER(C.c_float), vp, vp, i32]
+        l.rtxh_scene_update.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
         l.rtxh_texture_load.argtypes = [C.c_char_p, i32, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64), C.POINTER(RtxTextureDesc)]
         l.rtxh_texture_free.argtypes = [C.POINTER(C.c_float)]
         l.rtxh_image_load.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.POINTER(C.c_uint8))]
@@ -131,6 +133,33 @@ class Tlas:
             lib().rtxh_tlas_destroy(self.h)
         except Exception:
             pass
+
+
+class DynamicScene:
+    """Per-frame state of a scene whose instances move: Scene::update (Scene.cpp:139-171) in two native calls per frame."""
+
+    def __init__(self, scene: sio.Scene, positions, rotations):
+        self.n = len(scene.instances)
+        self.pos = np.ascontiguousarray(positions, np.float32).reshape(self.n, 3).copy()
+        self.rot = np.ascontiguousarray(rotations, np.float32).reshape(self.n, 4).copy()
+        self.time = C.c_float(0.0)
+        self.blas_ids = np.ascontiguousarray(scene.instances["blas_id"], np.int32)
+        self.roots = np.concatenate([np.concatenate([b.nodes[0]["aabb_min"], b.nodes[0]["aabb_max"]]) for b in scene.blas]).astype(np.float32)
+        self.tlas = Tlas(self.n)
+        self.instances = np.zeros(self.n, sio.INSTANCE)
+        self.nodes = np.zeros(2 * self.n, sio.BVH_NODE)
+        self.indices = np.zeros(self.n, np.int32)
+
+    def animate_dynamic(self, delta: float):
+        assert lib().rtxh_scene_dynamic_animate(C.c_float(delta), C.byref(self.time), self.pos.ctypes.data, self.rot.ctypes.data, self.n) == 0
+
+    def update(self):
+        """-> (instances, tlas_nodes, tlas_indices) for rtx_set_frame"""
+        nc = C.c_int32()
+        rc = lib().rtxh_scene_update(self.tlas.h, self.n, self.pos.ctypes.data, self.rot.ctypes.data, self.blas_ids.ctypes.data, self.roots.ctypes.data,
+                                     self.instances.ctypes.data, self.nodes.ctypes.data, self.indices.ctypes.data, C.byref(nc))
+        assert rc == 0, rc
+        return self.instances, self.nodes[:nc.value], self.indices
 
 
 def load_obj(path: str):

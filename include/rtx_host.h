@@ -11,6 +11,8 @@
  *                             AABB.cpp:55-73, Matrix4::invert Matrix4.h:88-138)
  *   rtxh_plane_update        Plane::update                                Plane.cpp:3-11
  *   rtxh_quaternion_axis_angle  Quaternion::axis_angle                     Quaternion.h:26-36
+ *   rtxh_scene_update        Scene::update's tail: all Mesh::update + TLAS rebuild   Scene.cpp:166-170
+ *   rtxh_scene_dynamic_animate  SCENE_DYNAMIC's animation                   Scene.cpp:141-155
  *   rtxh_tlas_*              TopLevelBVH::init / build_bvh                TopLevelBVH.cpp:5-45
  *                            (BVHBuilders::build_bvh<Mesh> BVHBuilders.h:8-46,
  *                             BVHPartitions::{calculate_bounds,partition_sah,split_indices})
@@ -79,6 +81,14 @@ int rtxh_blas_build_reference_bvh(const float * positions, int32_t triangle_coun
 int rtxh_blas_build_reference_sbvh(const float * positions, int32_t triangle_count,
                                    rtx_bvh_node * nodes_out, int32_t node_capacity, int32_t * node_count_out,
                                    int32_t * order_out, int32_t order_capacity, int32_t * order_count_out);
+
+/* Scene::update in two calls (Scene.cpp:139-171).  rtxh_scene_dynamic_animate is the animation SCENE_DYNAMIC hard-codes (:141-155,
+ * instances 0..5; *time is the function-static `time`); rtxh_scene_update is the common tail (:166-170): Mesh::update for every
+ * instance, then the TLAS rebuild.  positions n*3, rotations n*4 (x,y,z,w), blas_root_aabbs: 6 floats (min, max) per BLAS id.        */
+int rtxh_scene_dynamic_animate(float delta, float * time, float * positions, float * rotations, int32_t instance_count);
+int rtxh_scene_update(rtxh_tlas * tlas, int32_t instance_count, const float * positions, const float * rotations, const int32_t * blas_ids,
+                      const float * blas_root_aabbs, rtx_instance * instances_out, rtx_bvh_node * tlas_nodes_out,
+                      int32_t * tlas_indices_out, int32_t * tlas_node_count_out);
 
 /* Appends the box-filter mip chain to level 0 (texels_rgb holds w*h float3 on entry and must have
  * room for w*h + w*h/3 + 1 texels); fills desc like Texture::load.                               */

@@ -109,3 +109,20 @@ def test_gpu_renders_rebuilt_frames(name, frames):
         out = r.render()
     cmp = util.compare_to_golden(out, g)
     assert cmp["stats_equal"] and cmp["max_abs"] < 1e-4 and cmp["packed_mismatch"] == 0, cmp
+
+
+@pytest.mark.parametrize("name,frames", [("dynamic", 3), ("tori16", 2), ("tori16_f1", 1)])
+def test_native_scene_update_reproduces_reference_frame_state(name, frames):
+    """The same sequence through the two native calls a frame loop makes (rtxh_scene_dynamic_animate + rtxh_scene_update)."""
+    sc, _ = util.load_golden(name)
+    pos, rot = initial_state("dynamic" if name == "dynamic" else "tori16")
+    dyn = host.DynamicScene(sc, np.array(pos, f32), np.array(rot, f32))
+    for _ in range(frames):
+        dyn.animate_dynamic(0.0166666667)
+        inst, nodes, idx = dyn.update()
+    assert inst["world"].tobytes() == sc.instances["world"].tobytes() and inst["world_inv"].tobytes() == sc.instances["world_inv"].tobytes()
+    assert np.array_equal(inst["blas_id"], sc.instances["blas_id"])
+    assert np.array_equal(idx, sc.tlas_indices) and len(nodes) == len(sc.tlas_nodes)
+    for k in range(len(nodes)):
+        if k != 1:
+            assert nodes[k].tobytes() == sc.tlas_nodes[k].tobytes(), k
