@@ -24,6 +24,7 @@
 #include "rtx_texture.h"
 #include "rtx_trace.h"
 #include "rtx_shade.h"
+#include "rtx_present.h"
 
 #define SLOT_BUDGET (48ll * 1000 * 1000)      // ray slots per batch of tiles (see plan_batch)
 
@@ -57,7 +58,7 @@ struct rtx_ctx {
     DevQueues q;
     DevBuf qb[20];
     size_t slots_alloc = 0, shadow_alloc = 0;
-    DevBuf d_counters, d_spill, d_fb_rgb, d_fb_packed;
+    DevBuf d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma;
     int trace_blocks_closest = 0, trace_blocks_any = 0, trace_blocks_count = 0;
 
     rtx_stats stats_acc; rtx_work_counters work_acc; uint32_t err_flags_acc = 0;
@@ -181,7 +182,7 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     for (auto & v : c->blas_allocs) for (void * p : v) hipFree(p);
     for (void * p : c->tex_allocs) hipFree(p);
     DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->f_tlas, &c->f_tlas_idx, &c->f_inst, &c->f_sph,
-                        &c->f_pln, &c->f_pl, &c->f_sl, &c->f_dl, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed };
+                        &c->f_pln, &c->f_pl, &c->f_sl, &c->f_dl, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma };
     for (DevBuf * b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf & b : c->qb) if (b.p) hipFree(b.p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
@@ -519,6 +520,34 @@ extern "C" int rtx_read_framebuffer(rtx_ctx * c, float * rgb_f32, uint32_t * pac
     HIP_OK(c, hipStreamSynchronize(c->stream));
     if (rgb_f32)    HIP_OK(c, hipMemcpy(rgb_f32, c->ext_rgb ? c->ext_rgb : c->d_fb_rgb.p, px * 12, hipMemcpyDeviceToHost));
     if (packed_u32) HIP_OK(c, hipMemcpy(packed_u32, c->ext_packed ? c->ext_packed : c->d_fb_packed.p, px * 4, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+// Window::draw_quad (Window.cpp:87-95): gamma 1/2.2 + optional FXAA over the packed frame, see rtx_present.h (parity unpinned vs GL)
+extern "C" int rtx_present(rtx_ctx * c, int32_t enable_fxaa, uint32_t * display_u32, void ** display_dev) {
+    if (!c) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    const size_t px = (size_t)c->cfg.width * c->cfg.height;
+    int rc = ensure(c, c->d_display, px * 4);
+    if (rc) return rc;
+    if (!c->d_gamma.p) {
+        rc = ensure(c, c->d_gamma, 256 * sizeof(float));
+        if (rc) return rc;
+        float lut[256];
+        for (int i = 0; i < 256; i++) lut[i] = powf((float)i / 255.0f, 1.0f / 2.2f);         // pow(texel, vec3(1 / 2.2)), once per 8-bit value (host libm)
+        HIP_OK(c, hipMemcpy(c->d_gamma.p, lut, sizeof(lut), hipMemcpyHostToDevice));
+    }
+    PresentArgs a;
+    a.packed = (const uint32_t *)(c->ext_packed ? c->ext_packed : c->d_fb_packed.p);
+    a.gamma_lut = (const float *)c->d_gamma.p; a.display = (uint32_t *)c->d_display.p;
+    a.width = c->cfg.width; a.height = c->cfg.height; a.fxaa = enable_fxaa ? 1 : 0;
+    hipLaunchKernelGGL(k_present, dim3((c->cfg.width + 15) / 16, (c->cfg.height + 15) / 16), dim3(256), 0, c->stream, a);   // after the frame, same stream
+    HIP_OK(c, hipGetLastError());
+    if (display_u32) {
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        HIP_OK(c, hipMemcpy(display_u32, c->d_display.p, px * 4, hipMemcpyDeviceToHost));
+    }
+    if (display_dev) *display_dev = c->d_display.p;
     return RTX_OK;
 }
 

@@ -8,11 +8,15 @@
 #include <string>
 #include "rtx_facade.hpp"
 
+// out path ending in .png: the DISPLAYED image (Window::draw_quad: gamma + FXAA) as PNG; anything else: the raw frame as PPM
+static bool wants_png(const char * p) { std::string s = p ? p : ""; return s.size() > 4 && s.substr(s.size() - 4) == ".png"; }
+
 static int report(const rtx::Window & window, const rtx::PerformanceStats & stats, const char * ppm) {
     uint64_t h = 1469598103934665603ull;
     for (uint32_t p : window.frame_buffer) for (int k = 0; k < 4; k++) { h ^= (p >> (8 * k)) & 0xff; h *= 1099511628211ull; }
     std::printf("{\"primary\": %lld, \"shadow\": %lld, \"reflection\": %lld, \"refraction\": %lld, \"fnv1a\": \"%016llx\"}\n",
                 stats.num_primary_rays, stats.num_shadow_rays, stats.num_reflection_rays, stats.num_refraction_rays, (unsigned long long)h);
+    if (ppm && wants_png(ppm)) return rtxh_image_save_png(ppm, window.display.data(), window.width, window.height);
     if (ppm) {
         FILE * f = std::fopen(ppm, "wb");
         if (!f) return 1;
@@ -40,6 +44,7 @@ int main(int argc, char ** argv) {
             rtx::Raytracer raytracer; raytracer.scene = &scene;
             rtx::PerformanceStats stats;
             raytracer.render_frame(window, stats);
+            if (argc > 6 && wants_png(argv[6])) raytracer.draw_quad(window);
             return report(window, stats, argc > 6 ? argv[6] : nullptr);
         } catch (const std::exception & e) { std::fprintf(stderr, "facade_demo: %s\n", e.what()); return 1; }
     }
@@ -58,7 +63,7 @@ int main(int argc, char ** argv) {
         rtx::Raytracer raytracer; raytracer.scene = &scene;
         rtx::PerformanceStats stats;
         raytracer.render_frame(window, stats);
-
+        if (argc > 7 && wants_png(argv[7])) raytracer.draw_quad(window);
         return report(window, stats, argc > 7 ? argv[7] : nullptr);
     } catch (const std::exception & e) { std::fprintf(stderr, "facade_demo: %s\n", e.what()); return 1; }
     return 0;

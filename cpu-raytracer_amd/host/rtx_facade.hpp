@@ -84,6 +84,7 @@ public:
     const int tile_count_x, tile_count_y;
     std::vector<uint32_t> frame_buffer;       // 0x00RRGGBB, as Window::plot packs it
     std::vector<float>    frame_rgb;          // linear fp32 before quantisation
+    std::vector<uint32_t> display;            // what draw_quad puts on screen (gamma + FXAA), filled by Raytracer::draw_quad
     Window(int w, int h) : width(w), height(h), tile_count_x((w + 31) / 32), tile_count_y((h + 31) / 32),
                            frame_buffer((size_t)w * h), frame_rgb((size_t)w * h * 3) {}
 };
@@ -263,6 +264,12 @@ struct Raytracer {                  // Raytracer.h:11-18
         render_tiles(window, tile, 1, 1, stats);
     }
     void render_frame(Window & window, PerformanceStats & stats) const { render_tiles(window, 0, 1, window.tile_count_x * window.tile_count_y, stats); }
+
+    // Window::draw_quad (Window.cpp:87-95) without a GL context: the frame through the reference's gamma / FXAA shaders (rtx_present)
+    void draw_quad(Window & window, bool enable_fxaa = true /* ENABLE_FXAA, Config.h:20 */) const {
+        window.display.resize((size_t)window.width * window.height);
+        scene->check(rtx_present(scene->context(), enable_fxaa ? 1 : 0, window.display.data(), nullptr), "rtx_present");
+    }
 
     void render_tiles(Window & window, int first, int stride, int count, PerformanceStats & stats) const {
         rtx_ctx * c = scene->context();

@@ -429,6 +429,52 @@ extern "C" int rtxh_image_load(const char * path, int32_t * width, int32_t * hei
 
 extern "C" int rtxh_image_free(uint8_t * rgba) { free(rgba); return RTX_OK; }
 
+// A frame (Window::frame_buffer layout, 0x00RRGGBB) as an 8-bit RGB PNG: filter 0 rows in stored (uncompressed) deflate blocks.
+extern "C" int rtxh_image_save_png(const char * path, const uint32_t * packed, int32_t width, int32_t height) {
+    if (!path || !packed || width <= 0 || height <= 0) return RTX_ERR_INVALID_ARG;
+    static uint32_t crc_table[256]; static bool crc_ready = false;
+    if (!crc_ready) { for (uint32_t n = 0; n < 256; n++) { uint32_t c = n; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; crc_table[n] = c; } crc_ready = true; }
+    auto crc = [&](const uint8_t * d, size_t n, uint32_t c) { for (size_t i = 0; i < n; i++) c = crc_table[(c ^ d[i]) & 255] ^ (c >> 8); return c; };
+    Bytes raw;
+    raw.reserve(((size_t)width * 3 + 1) * height);
+    for (int y = 0; y < height; y++) {
+        raw.push_back(0);
+        for (int x = 0; x < width; x++) { const uint32_t p = packed[(size_t)y * width + x]; raw.push_back((uint8_t)(p >> 16)); raw.push_back((uint8_t)(p >> 8)); raw.push_back((uint8_t)p); }
+    }
+    Bytes z;
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        const size_t n = raw.size() - off < 65535 ? raw.size() - off : 65535;
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back((uint8_t)n); z.push_back((uint8_t)(n >> 8)); z.push_back((uint8_t)~n); z.push_back((uint8_t)(~n >> 8));
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        for (size_t i = 0; i < n; i++) { a = (a + raw[off + i]) % 65521u; b = (b + a) % 65521u; }
+        if (off + n >= raw.size()) break;
+    }
+    const uint32_t adler = (b << 16) | a;
+    for (int k = 3; k >= 0; k--) z.push_back((uint8_t)(adler >> (8 * k)));
+    FILE * f = fopen(path, "wb");
+    if (!f) return RTX_ERR_STATE;
+    auto chunk = [&](const char * tag, const uint8_t * d, size_t n) {
+        uint8_t len[4] = { (uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n };
+        fwrite(len, 1, 4, f); fwrite(tag, 1, 4, f); if (n) fwrite(d, 1, n, f);
+        uint32_t c = crc((const uint8_t *)tag, 4, 0xffffffffu); c = crc(d, n, c) ^ 0xffffffffu;
+        uint8_t cb[4] = { (uint8_t)(c >> 24), (uint8_t)(c >> 16), (uint8_t)(c >> 8), (uint8_t)c };
+        fwrite(cb, 1, 4, f);
+    };
+    static const uint8_t sig[8] = { 137, 80, 78, 71, 13, 10, 26, 10 };
+    fwrite(sig, 1, 8, f);
+    uint8_t ihdr[13] = { (uint8_t)(width >> 24), (uint8_t)(width >> 16), (uint8_t)(width >> 8), (uint8_t)width,
+                         (uint8_t)(height >> 24), (uint8_t)(height >> 16), (uint8_t)(height >> 8), (uint8_t)height, 8, 2, 0, 0, 0 };
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), z.size());
+    chunk("IEND", nullptr, 0);
+    const bool ok = !ferror(f);
+    fclose(f);
+    return ok ? RTX_OK : RTX_ERR_STATE;
+}
+
 extern "C" int rtxh_texture_load(const char * path, int32_t mipmap_mode, float ** texels_out, int64_t * texel_count_out, rtx_texture_desc * desc) {
     if (!path || !texels_out || !texel_count_out || !desc) return RTX_ERR_INVALID_ARG;
     int32_t w = 0, h = 0;

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "..", "csrc", "librtx_hip.so")
 EXPORTS = ["rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_blas", "rtx_upload_materials",
            "rtx_upload_texture", "rtx_upload_sky", "rtx_set_frame", "rtx_render_tiles", "rtx_synchronize", "rtx_get_stats",
            "rtx_read_framebuffer", "rtx_framebuffer_device_ptrs", "rtx_last_kernel_times", "rtx_enable_kernel_timing",
-           "rtx_bind_framebuffer", "rtx_set_stream", "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample"]
+           "rtx_bind_framebuffer", "rtx_set_stream", "rtx_present", "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample"]
 
 RTX_RENDER_COUNT_WORK = 1
 RTX_RENDER_SIMPLE_TRACE = 2
@@ -65,6 +65,7 @@ def load_library(path: Optional[str] = None):
     lib.rtx_enable_kernel_timing.argtypes = [vp, i32]
     lib.rtx_bind_framebuffer.argtypes = [vp, vp, vp]
     lib.rtx_set_stream.argtypes = [vp, vp]
+    lib.rtx_present.argtypes = [vp, i32, vp, C.POINTER(vp)]
     lib.rtx_debug_libm.argtypes = [vp, i32, vp, vp, vp, i32]
     lib.rtx_debug_texture_sample.argtypes = [vp, i32, vp, vp, i32]
     lib.rtx_debug_sky_sample.argtypes = [vp, vp, vp, i32]
@@ -153,6 +154,12 @@ class Renderer:
         packed = np.zeros((sc.height, sc.width), np.uint32)
         self._chk(self.lib.rtx_read_framebuffer(self.ctx, rgb.ctypes.data, packed.ctypes.data), "rtx_read_framebuffer")
         return rgb, packed
+
+    def present(self, fxaa: bool = True) -> np.ndarray:
+        """Window::draw_quad: the displayed image (gamma 1/2.2, optional FXAA) of the frame in the framebuffer, (h, w) 0x00RRGGBB."""
+        out = np.zeros((self.scene.height, self.scene.width), np.uint32)
+        self._chk(self.lib.rtx_present(self.ctx, 1 if fxaa else 0, out.ctypes.data, None), "rtx_present")
+        return out
 
     def device_ptrs(self):
         a, b = C.c_void_p(), C.c_void_p()

@@ -19,7 +19,7 @@ from .ctypes_structs import RtxCamera, RtxTextureDesc
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "host", "librtx_host.so")
 EXPORTS = ["rtxh_camera_basis", "rtxh_quaternion_axis_angle", "rtxh_scene_dynamic_animate", "rtxh_scene_update", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
-           "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_blas_build_reference_sbvh", "rtxh_texture_mips", "rtxh_texture_load", "rtxh_texture_free", "rtxh_image_load", "rtxh_image_free", "rtxh_atrium_generate", "rtxh_mesh_free",
+           "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_blas_build_reference_sbvh", "rtxh_texture_mips", "rtxh_texture_load", "rtxh_texture_free", "rtxh_image_load", "rtxh_image_free", "rtxh_image_save_png", "rtxh_atrium_generate", "rtxh_mesh_free",
            "rtxh_obj_load", "rtxh_obj_free"]
 
 PI = np.float32(3.14159265359)          # Util.h:8
@@ -61,6 +61,7 @@ def lib():
         l.rtxh_texture_free.argtypes = [C.POINTER(C.c_float)]
         l.rtxh_image_load.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.POINTER(C.c_uint8))]
         l.rtxh_image_free.argtypes = [C.POINTER(C.c_uint8)]
+        l.rtxh_image_save_png.argtypes = [C.c_char_p, vp, i32, i32]
         l.rtxh_blas_build_reference_sbvh.argtypes = [vp, i32, vp, i32, C.POINTER(i32), vp, i32, C.POINTER(i32)]
         l.rtxh_obj_load.argtypes = [C.c_char_p, C.POINTER(RtxhObj)]
         l.rtxh_obj_free.argtypes = [C.POINTER(RtxhObj)]
@@ -272,6 +273,14 @@ def load_image(path: str) -> np.ndarray:
     out = np.ctypeslib.as_array(p, (h.value, w.value, 4)).copy()
     lib().rtxh_image_free(p)
     return out
+
+
+def save_png(path: str, packed: np.ndarray) -> None:
+    """(h, w) uint32 0x00RRGGBB frame -> RGB PNG."""
+    p = np.ascontiguousarray(packed, np.uint32)
+    rc = lib().rtxh_image_save_png(path.encode(), p.ctypes.data, p.shape[1], p.shape[0])
+    if rc:
+        raise ValueError(f"rtxh_image_save_png({path!r}) failed with status {rc}")
 
 
 def load_texture(path: str, mipmap_mode: bool = True) -> sio.Texture:

@@ -278,6 +278,13 @@ int rtx_get_stats(rtx_ctx * ctx, rtx_stats * stats, rtx_work_counters * work);
  * may be NULL.  Pixels of tiles that were never rendered are zero.            */
 int rtx_read_framebuffer(rtx_ctx * ctx, float * rgb_f32, uint32_t * packed_u32);
 
+/* Window::draw_quad (Window.cpp:87-95): what the window would show.  The packed frame is drawn through the reference's
+ * full-screen shaders — gamma 1/2.2 and, with enable_fxaa (ENABLE_FXAA, Config.h:20), Data/Shaders/fragment_fxaa.glsl — by one
+ * HIP kernel queued behind the frame.  display_u32 (host, width*height 0x00RRGGBB, may be NULL) receives the image after a
+ * stream synchronise; *display_dev (may be NULL) its device address.  Parity with the GL path is UNPINNED (no GL driver to run
+ * the reference's shaders); the kernel equals oracle `orc_present` bit for bit, which documents the conventions assumed.        */
+int rtx_present(rtx_ctx * ctx, int32_t enable_fxaa, uint32_t * display_u32, void ** display_dev);
+
 /* Device addresses of the same two buffers (for RCCL / zero-copy consumers). */
 int rtx_framebuffer_device_ptrs(rtx_ctx * ctx, void ** rgb_f32_dev, void ** packed_u32_dev);
 

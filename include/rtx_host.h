@@ -105,6 +105,8 @@ int rtxh_texture_free(float * texels);
 /* The decode step alone: width*height RGBA8 pixels, top row first (malloc'ed; free with rtxh_image_free). */
 int rtxh_image_load(const char * path, int32_t * width, int32_t * height, uint8_t ** rgba_out);
 int rtxh_image_free(uint8_t * rgba);
+/* Screenshot: a frame in Window::frame_buffer layout (0x00RRGGBB, e.g. from rtx_read_framebuffer or rtx_present) as an RGB PNG. */
+int rtxh_image_save_png(const char * path, const uint32_t * packed, int32_t width, int32_t height);
 
 /* Procedural "atrium": returns the triangle count for a detail level, then fills caller arrays.   */
 typedef struct rtxh_mesh {

@@ -70,6 +70,8 @@ def lib():
         _lib.orc_trace_any.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_void_p, C.c_float]
         _lib.orc_ewa_table.restype = None
         _lib.orc_ewa_table.argtypes = [C.c_void_p]
+        _lib.orc_present.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        _lib.orc_present.restype = C.c_int
     return _lib
 
 
@@ -127,3 +129,22 @@ class OracleScene:
         if want_dist:
             out["dist"] = dist
         return out
+
+
+def gamma_lut() -> np.ndarray:
+    """pow(i / 255, 1 / 2.2) per 8-bit value with the host libm's powf (what rtx_present evaluates on the host, too)."""
+    libm = C.CDLL("libm.so.6")
+    libm.powf.restype = C.c_float; libm.powf.argtypes = [C.c_float, C.c_float]
+    e = np.float32(1.0) / np.float32(2.2)
+    return np.array([libm.powf(float(np.float32(i) / np.float32(255.0)), float(e)) for i in range(256)], np.float32)
+
+
+def present(packed: np.ndarray, fxaa: bool = True) -> np.ndarray:
+    """Window::draw_quad restated (parity unpinned vs GL, see rt_oracle.h): packed (h, w) uint32 -> displayed (h, w) uint32."""
+    p = np.ascontiguousarray(packed, np.uint32)
+    h, w = p.shape
+    out = np.zeros((h, w), np.uint32)
+    lut = gamma_lut()
+    rc = lib().orc_present(p.ctypes.data, w, h, 1 if fxaa else 0, lut.ctypes.data, out.ctypes.data)
+    assert rc == 0, rc
+    return out

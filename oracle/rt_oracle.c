@@ -967,3 +967,70 @@ int orc_trace_any(const orc_scene * scene, const float origin[3], const float di
     counters_t c; memset(&c, 0, sizeof(c));
     return scene_intersect(scene, v3p(origin), v3p(direction), max_distance, &c);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Window::draw_quad -> vertex.glsl + fragment_fxaa.glsl / fragment_identity.glsl  (PARITY UNPINNED, see rt_oracle.h)
+ *
+ * Conventions where OpenGL leaves room (all stated so that the HIP kernel and this restatement agree bit for bit):
+ *  - the fragment of window pixel (i, j from the top) receives in_uv = ((i + 0.5) / W, (j + 0.5) / H) (vertex.glsl:9-13 through a
+ *    perspective-free interpolation; evaluated here as (float(i) + 0.5f) * (1.0f / W));
+ *  - texture2D with GL_NEAREST / GL_REPEAT (Window.cpp:48-49 and the GL defaults): texel = floor(fract(u) * size);
+ *  - RGBA8 texel channels are c / 255; pow(c, 1 / 2.2) is looked up per 8-bit value (table supplied by the caller);
+ *  - `vec2(-inv_screen_size.x, -inv_screen_size)` (fragment_fxaa.glsl:26-29) takes the FIRST component of the vec2: both offsets
+ *    are 1 / SCREEN_WIDTH;
+ *  - the RGB8 colour buffer stores round-to-nearest-even(clamp(c, 0, 1) * 255).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { const uint32_t * px; int w, h; const float * lut; } screen_t;
+
+static v3 get_screen(const screen_t * s, float u, float v) {                 /* fragment_fxaa.glsl:16-18 */
+    float fu = u - floorf(u), fv = v - floorf(v);
+    int x = (int)(fu * (float)s->w), y = (int)(fv * (float)s->h);
+    if (x > s->w - 1) x = s->w - 1;
+    if (y > s->h - 1) y = s->h - 1;
+    uint32_t p = s->px[(size_t)y * s->w + x];
+    return V3(s->lut[(p >> 16) & 255], s->lut[(p >> 8) & 255], s->lut[p & 255]);
+}
+
+static float luma_of(v3 c) { return 0.299f * c.x + 0.587f * c.y + 0.114f * c.z; }   /* dot(luma, c), :22 */
+
+static uint32_t to_unorm8(float c) {
+    float x = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
+    return (uint32_t)lrintf(x * 255.0f);
+}
+
+int orc_present(const uint32_t * packed, int32_t width, int32_t height, int32_t fxaa, const float * gamma_lut, uint32_t * display) {
+    if (!packed || !gamma_lut || !display || width <= 0 || height <= 0) return RTX_ERR_INVALID_ARG;
+    const screen_t s = { packed, width, height, gamma_lut };
+    const float inv_x = 1.0f / (float)width, inv_y = 1.0f / (float)height;   /* Window.cpp:57 */
+    const float REDUCE_MIN = 1.0f / 128.0f, REDUCE_MUL = 1.0f / 8.0f, SPAN_MAX = 8.0f;   /* :11-13 */
+    for (int j = 0; j < height; j++) for (int i = 0; i < width; i++) {
+        const float u = ((float)i + 0.5f) * inv_x, v = ((float)j + 0.5f) * inv_y;
+        v3 out;
+        if (!fxaa) out = get_screen(&s, u, v);                                /* fragment_identity.glsl:14-16 */
+        else {                                                                /* fragment_fxaa.glsl:21-70 */
+            const float luma_tl = luma_of(get_screen(&s, u + -inv_x, v + -inv_x));
+            const float luma_tr = luma_of(get_screen(&s, u +  inv_x, v + -inv_x));
+            const float luma_bl = luma_of(get_screen(&s, u + -inv_x, v +  inv_x));
+            const float luma_br = luma_of(get_screen(&s, u +  inv_x, v +  inv_x));
+            const float luma_m  = luma_of(get_screen(&s, u, v));
+            const float luma_min = fminf(fminf(fminf(luma_tl, luma_tr), fminf(luma_bl, luma_br)), luma_m);
+            const float luma_max = fmaxf(fmaxf(fmaxf(luma_tl, luma_tr), fmaxf(luma_bl, luma_br)), luma_m);
+            float dir_x = (luma_bl + luma_br) - (luma_tl + luma_tr);
+            float dir_y = (luma_tl + luma_bl) - (luma_tr + luma_br);
+            const float reduce = fmaxf(REDUCE_MIN, (luma_tl + luma_tr + luma_bl + luma_br) * 0.25f * REDUCE_MUL);
+            const float adjust = 1.0f / (fminf(fabsf(dir_x), fabsf(dir_y)) + reduce);
+            dir_x = fminf(fmaxf(dir_x * adjust, -SPAN_MAX), SPAN_MAX) * inv_x;
+            dir_y = fminf(fmaxf(dir_y * adjust, -SPAN_MAX), SPAN_MAX) * inv_y;
+            const float k1 = 1.0f / 3.0f - 0.5f, k2 = 2.0f / 3.0f - 0.5f, k0 = 0.0f / 3.0f - 0.5f, k3 = 3.0f / 3.0f - 0.5f;
+            const v3 a1 = get_screen(&s, u + dir_x * k1, v + dir_y * k1), a2 = get_screen(&s, u + dir_x * k2, v + dir_y * k2);
+            const v3 b1 = get_screen(&s, u + dir_x * k0, v + dir_y * k0), b2 = get_screen(&s, u + dir_x * k3, v + dir_y * k3);
+            const v3 result_a = V3(0.5f * (a1.x + a2.x), 0.5f * (a1.y + a2.y), 0.5f * (a1.z + a2.z));
+            const v3 result_b = V3(0.5f * (b1.x + b2.x), 0.5f * (b1.y + b2.y), 0.5f * (b1.z + b2.z));
+            const v3 result = V3(0.5f * (result_a.x + result_b.x), 0.5f * (result_a.y + result_b.y), 0.5f * (result_a.z + result_b.z));
+            const float luma_result = luma_of(result);
+            out = (luma_result < luma_min || luma_result > luma_max) ? result_a : result;
+        }
+        display[(size_t)j * width + i] = (to_unorm8(out.x) << 16) | (to_unorm8(out.y) << 8) | to_unorm8(out.z);
+    }
+    return RTX_OK;
+}

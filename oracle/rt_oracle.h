@@ -49,6 +49,12 @@ int orc_render_tiles(const orc_scene * scene, int32_t first_tile, int32_t tile_s
                      float * rgb, uint32_t * packed, float * dist,
                      rtx_stats * stats, rtx_work_counters * work, int32_t threads);
 
+/* Window::draw_quad (Window.cpp:87-95): the packed frame through the full-screen triangle of Data/Shaders/vertex.glsl and
+ * fragment_fxaa.glsl (fxaa != 0, Config.h:20) or fragment_identity.glsl, into an 8-bit display image (0x00RRGGBB).
+ * PARITY UNPINNED: a GL driver runs the reference's shaders and none exists here; conventions assumed where GL leaves room are
+ * listed at the implementation.  gamma_lut: 256 floats, pow(i / 255, 1 / 2.2) (the caller evaluates it once, with its libm). */
+int orc_present(const uint32_t * packed, int32_t width, int32_t height, int32_t fxaa, const float * gamma_lut, uint32_t * display);
+
 /* Unit entry points (each mirrors one reference function). */
 int      orc_aabb_intersect(const rtx_bvh_node * node, const float origin[3], const float inv_direction[3], float max_distance);
 void     orc_texture_sample(const orc_texture * tex, int32_t texture_mode, int32_t mip_filter, float max_anisotropy,

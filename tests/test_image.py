@@ -69,3 +69,24 @@ def test_decoder_errors(tmp_path):
     broken = bytearray(png); broken[8 + 8 + 8] = 3                                      # bit depth 3
     assert status(bytes(broken)) == 1
     assert status(b"") == 1
+
+
+def test_png_writer_round_trips_through_the_decoder(tmp_path):
+    rng = np.random.default_rng(3)
+    for h, w in ((1, 1), (7, 300), (200, 333)):                                          # the last one needs several stored deflate blocks
+        frame = rng.integers(0, 1 << 24, (h, w), dtype=np.uint32)
+        p = str(tmp_path / f"f{h}x{w}.png")
+        host.save_png(p, frame)
+        back = host.load_image(p)
+        assert back.shape == (h, w, 4) and np.all(back[..., 3] == 255)
+        assert np.array_equal((back[..., 0].astype(np.uint32) << 16) | (back[..., 1].astype(np.uint32) << 8) | back[..., 2], frame)
+        import zlib, struct
+        raw = open(p, "rb").read()                                                       # and a standard zlib accepts the stream + CRCs
+        pos, idat = 8, b""
+        while pos < len(raw):
+            n, tag = struct.unpack(">I4s", raw[pos:pos + 8])
+            assert zlib.crc32(raw[pos + 4:pos + 8 + n]) & 0xffffffff == struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0]
+            if tag == b"IDAT":
+                idat += raw[pos + 8:pos + 8 + n]
+            pos += 12 + n
+        assert len(zlib.decompress(idat)) == h * (3 * w + 1)
