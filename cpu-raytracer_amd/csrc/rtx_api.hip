@@ -60,6 +60,7 @@ struct rtx_ctx {
     size_t slots_alloc = 0, shadow_alloc = 0;
     DevBuf d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma;
     int trace_blocks_closest = 0, trace_blocks_any = 0, trace_blocks_count = 0;
+    bool use_uni = true;                 // production traversal: k_trace_uni (one 64-byte fetch per lane per iteration); RTX_TRACE_KERNEL=fast selects k_trace_fast
 
     rtx_stats stats_acc; rtx_work_counters work_acc; uint32_t err_flags_acc = 0;
     bool stats_pending = false;
@@ -160,9 +161,12 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     hipMemset(c->d_fb_packed.p, 0, px * 4);
 
     int bpc = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<false>, RTX_TRACE_BLOCK, 0);
+    if (const char * e = getenv("RTX_TRACE_KERNEL")) c->use_uni = strcmp(e, "fast") != 0;
+    if (c->use_uni) hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_uni<false>, RTX_TRACE_BLOCK, 0);
+    else            hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<false>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_closest = c->n_cu * (bpc > 0 ? bpc : 2);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<true>, RTX_TRACE_BLOCK, 0);
+    if (c->use_uni) hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_uni<true>, RTX_TRACE_BLOCK, 0);
+    else            hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<true>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_any = c->n_cu * (bpc > 0 ? bpc : 2);
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace<false, true>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_count = c->n_cu * (bpc > 0 ? bpc : 2);
@@ -214,11 +218,11 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
     c->blas_allocs[blas_id].clear();
 
     std::vector<float4> nd; convert_nodes(nodes, node_count, nd);
-    std::vector<float4> th((size_t)3 * (triangle_count > 0 ? triangle_count : 1));
+    std::vector<float4> th((size_t)RTX_TRI_STRIDE * (triangle_count > 0 ? triangle_count : 1), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     for (int i = 0; i < triangle_count; i++) {
-        th[3 * i]     = make_float4(tri_hot[i].position_0[0], tri_hot[i].position_0[1], tri_hot[i].position_0[2], 0.0f);
-        th[3 * i + 1] = make_float4(tri_hot[i].position_edge_1[0], tri_hot[i].position_edge_1[1], tri_hot[i].position_edge_1[2], 0.0f);
-        th[3 * i + 2] = make_float4(tri_hot[i].position_edge_2[0], tri_hot[i].position_edge_2[1], tri_hot[i].position_edge_2[2], 0.0f);
+        th[RTX_TRI_STRIDE * (size_t)i]     = make_float4(tri_hot[i].position_0[0], tri_hot[i].position_0[1], tri_hot[i].position_0[2], 0.0f);
+        th[RTX_TRI_STRIDE * (size_t)i + 1] = make_float4(tri_hot[i].position_edge_1[0], tri_hot[i].position_edge_1[1], tri_hot[i].position_edge_1[2], 0.0f);
+        th[RTX_TRI_STRIDE * (size_t)i + 2] = make_float4(tri_hot[i].position_edge_2[0], tri_hot[i].position_edge_2[1], tri_hot[i].position_edge_2[2], 0.0f);
     }
     void * dn = nullptr, * dt = nullptr, * dc = nullptr;
     HIP_OK(c, hipMalloc(&dn, nd.size() * 16)); c->blas_allocs[blas_id].push_back(dn);
@@ -449,6 +453,7 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
             launch_timed(c, "k_trace_closest", c->stream, [&] {
                 if (count_work)   hipLaunchKernelGGL((k_trace<false, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (simple)  hipLaunchKernelGGL((k_trace<false, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else if (c->use_uni) hipLaunchKernelGGL((k_trace_uni<false>), dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
                 else              hipLaunchKernelGGL((k_trace_fast<false>),   dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
             });
             launch_timed(c, "k_shade", c->stream, [&] {
@@ -462,17 +467,20 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
                     hipEventRecord(c->ev_shade0, c->stream);
                     hipStreamWaitEvent(c->any_stream, c->ev_shade0, 0);
                     launch_timed(c, "k_trace_any", c->any_stream, [&] {
-                        hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 0, 0); });
+                        if (c->use_uni) hipLaunchKernelGGL((k_trace_uni<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 0, 0);
+                        else hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 0, 0); });
                 }
                 if (level == levels - 1 && levels > 1) {
                     hipEventRecord(c->ev_shade_last, c->stream);
                     hipStreamWaitEvent(c->any_stream, c->ev_shade_last, 0);
                     launch_timed(c, "k_trace_any", c->any_stream, [&] {
-                        hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 1, levels - 1); });
+                        if (c->use_uni) hipLaunchKernelGGL((k_trace_uni<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 1, levels - 1);
+                        else hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 1, levels - 1); });
                 }
             } else launch_timed(c, "k_trace_any", c->stream, [&] {
                 if (count_work)   hipLaunchKernelGGL((k_trace<true, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (simple)  hipLaunchKernelGGL((k_trace<true, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else if (c->use_uni) hipLaunchKernelGGL((k_trace_uni<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
                 else              hipLaunchKernelGGL((k_trace_fast<true>),   dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
             });
         }

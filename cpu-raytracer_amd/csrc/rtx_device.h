@@ -11,6 +11,7 @@
 
 #define RTX_MAX_LEVELS   12          // NUMBER_OF_BOUNCES + 1 wavefront levels supported
 #ifndef RTX_LDS_STACK
+#define RTX_TRI_STRIDE   4           // float4 per hot triangle on the device: p0, e1, e2 + padding = one 64-byte line per triangle
 #define RTX_LDS_STACK    16          // traversal stack entries kept in LDS per lane (4 KiB per wave); deeper entries spill to HBM
 #endif
 #define RTX_WAVE         64

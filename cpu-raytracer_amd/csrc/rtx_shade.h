@@ -43,7 +43,7 @@ RTX_D void rebuild_triangle_hit(const DevScene & sc, int inst, int tri, float t,
     r.dD_dx = xform_dir(I.world_inv, wr.dD_dx);
     r.dD_dy = xform_dir(I.world_inv, wr.dD_dy);
 
-    const float4 e1 = B.tri_hot[3 * tri + 1], e2 = B.tri_hot[3 * tri + 2];
+    const float4 e1 = B.tri_hot[RTX_TRI_STRIDE * tri + 1], e2 = B.tri_hot[RTX_TRI_STRIDE * tri + 2];
     const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
     const rtx_triangle_cold & tc = B.tri_cold[tri];
     const v3 n_edge_1 = v3p(tc.normal_edge_1), n_edge_2 = v3p(tc.normal_edge_2);

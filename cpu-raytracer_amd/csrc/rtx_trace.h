@@ -321,7 +321,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
                     // BLAS leaf: triangle_trace / triangle_intersect (BottomLevelBVH.cpp:214-346)
                     for (int i = first; i < first + cnt; i++) {
                         if (COUNT) n_tri++;
-                        const float4 p0 = gld(cur_tris, 3 * i), e1 = gld(cur_tris, 3 * i + 1), e2 = gld(cur_tris, 3 * i + 2);
+                        const float4 p0 = gld(cur_tris, RTX_TRI_STRIDE * i), e1 = gld(cur_tris, RTX_TRI_STRIDE * i + 1), e2 = gld(cur_tris, RTX_TRI_STRIDE * i + 2);
                         const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
                         const v3 h = vcross(cd, edge_2);
                         const float a = vdot(edge_1, h);
@@ -576,7 +576,7 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
                 const int first = cur_first, cnt = cur_cnt;
                 if (floor_sp >= 0) {
                     for (int i = first; i < first + cnt; i++) {
-                        const float4 p0 = gld(cur_tris, 3 * i), e1 = gld(cur_tris, 3 * i + 1), e2 = gld(cur_tris, 3 * i + 2);
+                        const float4 p0 = gld(cur_tris, RTX_TRI_STRIDE * i), e1 = gld(cur_tris, RTX_TRI_STRIDE * i + 1), e2 = gld(cur_tris, RTX_TRI_STRIDE * i + 2);
                         const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
                         const v3 h = vcross(cd, edge_2);
                         const float a = vdot(edge_1, h);
