@@ -60,7 +60,6 @@ struct rtx_ctx {
     size_t slots_alloc = 0, shadow_alloc = 0;
     DevBuf d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma;
     int trace_blocks_closest = 0, trace_blocks_any = 0, trace_blocks_count = 0;
-    bool use_uni = true;                 // production traversal: k_trace_uni (one 64-byte fetch per lane per iteration); RTX_TRACE_KERNEL=fast selects k_trace_fast
 
     rtx_stats stats_acc; rtx_work_counters work_acc; uint32_t err_flags_acc = 0;
     bool stats_pending = false;
@@ -161,12 +160,9 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     hipMemset(c->d_fb_packed.p, 0, px * 4);
 
     int bpc = 0;
-    if (const char * e = getenv("RTX_TRACE_KERNEL")) c->use_uni = strcmp(e, "fast") != 0;
-    if (c->use_uni) hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_uni<false>, RTX_TRACE_BLOCK, 0);
-    else            hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<false>, RTX_TRACE_BLOCK, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<false>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_closest = c->n_cu * (bpc > 0 ? bpc : 2);
-    if (c->use_uni) hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_uni<true>, RTX_TRACE_BLOCK, 0);
-    else            hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<true>, RTX_TRACE_BLOCK, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<true>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_any = c->n_cu * (bpc > 0 ? bpc : 2);
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace<false, true>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_count = c->n_cu * (bpc > 0 ? bpc : 2);
@@ -453,7 +449,6 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
             launch_timed(c, "k_trace_closest", c->stream, [&] {
                 if (count_work)   hipLaunchKernelGGL((k_trace<false, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (simple)  hipLaunchKernelGGL((k_trace<false, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else if (c->use_uni) hipLaunchKernelGGL((k_trace_uni<false>), dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
                 else              hipLaunchKernelGGL((k_trace_fast<false>),   dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
             });
             launch_timed(c, "k_shade", c->stream, [&] {
@@ -467,20 +462,17 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
                     hipEventRecord(c->ev_shade0, c->stream);
                     hipStreamWaitEvent(c->any_stream, c->ev_shade0, 0);
                     launch_timed(c, "k_trace_any", c->any_stream, [&] {
-                        if (c->use_uni) hipLaunchKernelGGL((k_trace_uni<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 0, 0);
-                        else hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 0, 0); });
+                        hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 0, 0); });
                 }
                 if (level == levels - 1 && levels > 1) {
                     hipEventRecord(c->ev_shade_last, c->stream);
                     hipStreamWaitEvent(c->any_stream, c->ev_shade_last, 0);
                     launch_timed(c, "k_trace_any", c->any_stream, [&] {
-                        if (c->use_uni) hipLaunchKernelGGL((k_trace_uni<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 1, levels - 1);
-                        else hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 1, levels - 1); });
+                        hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 1, levels - 1); });
                 }
             } else launch_timed(c, "k_trace_any", c->stream, [&] {
                 if (count_work)   hipLaunchKernelGGL((k_trace<true, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (simple)  hipLaunchKernelGGL((k_trace<true, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else if (c->use_uni) hipLaunchKernelGGL((k_trace_uni<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
                 else              hipLaunchKernelGGL((k_trace_fast<true>),   dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
             });
         }
