@@ -43,9 +43,18 @@ RTX_D void rebuild_triangle_hit(const DevScene & sc, int inst, int tri, float t,
     r.dD_dx = xform_dir(I.world_inv, wr.dD_dx);
     r.dD_dy = xform_dir(I.world_inv, wr.dD_dy);
 
-    const float4 e1 = B.tri_hot[RTX_TRI_STRIDE * tri + 1], e2 = B.tri_hot[RTX_TRI_STRIDE * tri + 2];
+    // pointers out of the DevBlas table: global memory, told to the compiler (global_load instead of flat_load, as in rtx_trace.h)
+    const float4 e1 = gld(RTX_GPTR(B.tri_hot), RTX_TRI_STRIDE * tri + 1), e2 = gld(RTX_GPTR(B.tri_hot), RTX_TRI_STRIDE * tri + 2);
     const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
-    const rtx_triangle_cold & tc = B.tri_cold[tri];
+    rtx_triangle_cold tc;                                        // 64-byte record = 4 x dwordx4
+    {
+        const rtx_gptr cp = RTX_GPTR(B.tri_cold + tri);
+        const float4 c0 = gld(cp, 0), c1 = gld(cp, 1), c2 = gld(cp, 2), c3 = gld(cp, 3);
+        tc.tex_coord_0[0] = c0.x; tc.tex_coord_0[1] = c0.y; tc.tex_coord_edge_1[0] = c0.z; tc.tex_coord_edge_1[1] = c0.w;
+        tc.tex_coord_edge_2[0] = c1.x; tc.tex_coord_edge_2[1] = c1.y; tc.normal_0[0] = c1.z; tc.normal_0[1] = c1.w;
+        tc.normal_0[2] = c2.x; tc.normal_edge_1[0] = c2.y; tc.normal_edge_1[1] = c2.z; tc.normal_edge_1[2] = c2.w;
+        tc.normal_edge_2[0] = c3.x; tc.normal_edge_2[1] = c3.y; tc.normal_edge_2[2] = c3.z; tc.material_id = as_i(c3.w);
+    }
     const v3 n_edge_1 = v3p(tc.normal_edge_1), n_edge_2 = v3p(tc.normal_edge_2);
     const v3 n = vadd(vadd(v3p(tc.normal_0), vmuls(n_edge_1, u)), vmuls(n_edge_2, v));
 

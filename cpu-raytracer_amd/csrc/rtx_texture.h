@@ -17,7 +17,7 @@ RTX_D v3 fetch_texel(TexCtx & tc, int x, int y, int level) {        // Texture.c
     x = mod_pos(x, lw);
     y = mod_pos(y, lh);
     tc.fetches++;
-    const float * p = tc.t->texels + 3 * (size_t)(offset + x + y * lw);
+    const __attribute__((address_space(1))) float * p = (const __attribute__((address_space(1))) float *)(const void *)tc.t->texels + 3 * (size_t)(offset + x + y * lw);   // texel arrays live in HBM: global_load
     return V3(p[0], p[1], p[2]);
 }
 
