@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra passes (serial-mode timings, culling figure): use under rocprofv3 so its per-kernel averages cover only the benchmark's own launches")
     ap.add_argument("--serial", action="store_true", help="RTX_RENDER_SERIAL for the timed loop (one stream per frame); default when more than one frame is in flight")
     ap.add_argument("--overlap", action="store_true", help="force the two-stream intra-frame overlap even with several frames in flight")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="A/B: no HIP events around the launches of the timed region (roofline fields become null)")
     ap.add_argument("--cull", action="store_true", help="time with RTX_RENDER_CULL_DEAD_SHADOW_RAYS as the main figure (default: reported as an extra)")
     args = ap.parse_args()
 
@@ -159,7 +160,7 @@ def main():
         step()
     sync()
     for sl in slots:
-        sl.r.enable_timing(True)
+        sl.r.enable_timing(not args.no_kernel_timing)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

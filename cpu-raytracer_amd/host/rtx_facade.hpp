@@ -63,6 +63,8 @@ struct Camera {                     // Camera.h:10-30
     void resize(int w, int h) { width = w; height = h; }                                   // Camera.cpp:5-16
     bool basis_is_baked = false;   // set when the basis came from a scene file instead of position/rotation/fov
     void update() { if (!basis_is_baked && rtxh_camera_basis(width, height, fov, position, rotation, &basis)) throw std::runtime_error("camera"); }   // :44-47
+    // Camera::update(delta, keys), Camera.cpp:18-48: keys = OR of RTXH_KEY_* (what SDL_GetKeyboardState reports in the reference)
+    void update(float delta, uint32_t keys) { if (rtxh_camera_update(delta, keys, position, rotation)) throw std::runtime_error("camera"); update(); }
 };
 
 struct Mesh {                       // Mesh.h:8-27 (transform + shared BLAS)
@@ -279,6 +281,30 @@ struct Raytracer {                  // Raytracer.h:11-18
         stats.num_primary_rays += (long long)s.num_primary_rays; stats.num_shadow_rays += (long long)s.num_shadow_rays;
         stats.num_reflection_rays += (long long)s.num_reflection_rays; stats.num_refraction_rays += (long long)s.num_refraction_rays;
         scene->check(rtx_read_framebuffer(c, window.frame_rgb.data(), window.frame_buffer.data()), "rtx_read_framebuffer");
+    }
+};
+
+// The numbers of the reference's HUD (Main.cpp:59-95): frame time averaged over the last 100 frames, whole-second fps, MRays/s
+// = per-frame ray counts x fps x 1e-6.  Call frame(delta_seconds, stats) once per frame, like the body of the game loop.
+struct FrameCounters {
+    static const int TOTAL_TIMING_COUNT = 100;                 // Main.cpp:15
+    float timings[TOTAL_TIMING_COUNT] = { 0 };
+    int   current_frame = 0, frames = 0, fps = 0;
+    float second = 0.0f, delta_time = 0.0f, avg = 0.0f;
+    float mrays_primary = 0, mrays_shadow = 0, mrays_reflection = 0, mrays_refraction = 0, mrays_total = 0;
+    void frame(float delta, const PerformanceStats & s) {
+        delta_time = delta;
+        timings[current_frame++ % TOTAL_TIMING_COUNT] = delta_time;
+        avg = 0.0f;
+        const int count = current_frame < TOTAL_TIMING_COUNT ? current_frame : TOTAL_TIMING_COUNT;
+        for (int i = 0; i < count; i++) avg += timings[i];
+        avg /= count;
+        frames++;
+        second += delta_time;
+        while (second >= 1.0f) { second -= 1.0f; fps = frames; frames = 0; }
+        mrays_primary = float(s.num_primary_rays * fps) * 1e-6f;       mrays_shadow = float(s.num_shadow_rays * fps) * 1e-6f;
+        mrays_reflection = float(s.num_reflection_rays * fps) * 1e-6f; mrays_refraction = float(s.num_refraction_rays * fps) * 1e-6f;
+        mrays_total = mrays_primary + mrays_shadow + mrays_reflection + mrays_refraction;
     }
 };
 

@@ -175,6 +175,29 @@ inline Q q_nlerp(Q a, Q b, float t) {                                           
 }
 }  // namespace
 
+// Camera::update's input half (Camera.cpp:18-39): WASD / shift / space move at 10 units/s, the arrow keys turn at 3 rad/s; each key
+// acts on the state the previous key left (position first, then rotation; `right` and `forward` are taken once, before any of it).
+extern "C" int rtxh_camera_update(float delta, uint32_t keys, float position[3], float rotation[4]) {
+    if (!position || !rotation) return RTX_ERR_INVALID_ARG;
+    const float MOVEMENT_SPEED = 10.0f, ROTATION_SPEED = 3.0f;
+    const V right = rotate(rotation, mk(1.0f, 0.0f, 0.0f)), forward = rotate(rotation, mk(0.0f, 0.0f, 1.0f));
+    V p = mk(position[0], position[1], position[2]);
+    if (keys & RTXH_KEY_W) p = p + forward * MOVEMENT_SPEED * delta;
+    if (keys & RTXH_KEY_A) p = p - right   * MOVEMENT_SPEED * delta;
+    if (keys & RTXH_KEY_S) p = p - forward * MOVEMENT_SPEED * delta;
+    if (keys & RTXH_KEY_D) p = p + right   * MOVEMENT_SPEED * delta;
+    if (keys & RTXH_KEY_LSHIFT) p.y -= MOVEMENT_SPEED * delta;
+    if (keys & RTXH_KEY_SPACE)  p.y += MOVEMENT_SPEED * delta;
+    Q r{ rotation[0], rotation[1], rotation[2], rotation[3] };
+    if (keys & RTXH_KEY_UP)    r = q_mul(q_axis_angle(right.x, right.y, right.z, -ROTATION_SPEED * delta), r);
+    if (keys & RTXH_KEY_DOWN)  r = q_mul(q_axis_angle(right.x, right.y, right.z, +ROTATION_SPEED * delta), r);
+    if (keys & RTXH_KEY_LEFT)  r = q_mul(q_axis_angle(0.0f, 1.0f, 0.0f, -ROTATION_SPEED * delta), r);
+    if (keys & RTXH_KEY_RIGHT) r = q_mul(q_axis_angle(0.0f, 1.0f, 0.0f, +ROTATION_SPEED * delta), r);
+    position[0] = p.x; position[1] = p.y; position[2] = p.z;
+    rotation[0] = r.x; rotation[1] = r.y; rotation[2] = r.z; rotation[3] = r.w;
+    return RTX_OK;
+}
+
 // The animation SCENE_DYNAMIC hard-codes into Scene::update (Scene.cpp:141-155): instances 0..5 move, *time accumulates delta.
 extern "C" int rtxh_scene_dynamic_animate(float delta, float * time, float * positions, float * rotations, int32_t instance_count) {
     if (!time || !positions || !rotations || instance_count < 6) return RTX_ERR_INVALID_ARG;

@@ -18,7 +18,7 @@ from .ctypes_structs import RtxCamera, RtxTextureDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "host", "librtx_host.so")
-EXPORTS = ["rtxh_camera_basis", "rtxh_quaternion_axis_angle", "rtxh_scene_dynamic_animate", "rtxh_scene_update", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
+EXPORTS = ["rtxh_camera_basis", "rtxh_camera_update", "rtxh_quaternion_axis_angle", "rtxh_scene_dynamic_animate", "rtxh_scene_update", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
            "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_blas_build_reference_sbvh", "rtxh_texture_mips", "rtxh_texture_load", "rtxh_texture_free", "rtxh_image_load", "rtxh_image_free", "rtxh_image_save_png", "rtxh_atrium_generate", "rtxh_mesh_free",
            "rtxh_obj_load", "rtxh_obj_free"]
 
@@ -55,6 +55,7 @@ def lib():
         l.rtxh_blas_build.argtypes = [vp, i32, i32, vp, C.POINTER(i32), vp]
         l.rtxh_blas_build_reference_bvh.argtypes = [vp, i32, vp, C.POINTER(i32), vp]
         l.rtxh_quaternion_axis_angle.argtypes = [vp, C.c_float, vp]
+        l.rtxh_camera_update.argtypes = [C.c_float, C.c_uint32, vp, vp]
         l.rtxh_scene_dynamic_animate.argtypes = [C.c_float, C.POINTER(C.c_float), vp, vp, i32]
         l.rtxh_scene_update.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
         l.rtxh_texture_load.argtypes = [C.c_char_p, i32, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64), C.POINTER(RtxTextureDesc)]
@@ -84,6 +85,19 @@ def axis_angle(axis: Sequence[float], angle: float) -> np.ndarray:
     a = _f32(axis)
     assert lib().rtxh_quaternion_axis_angle(a.ctypes.data, C.c_float(float(np.float32(angle))), out.ctypes.data) == 0
     return out
+
+
+KEYS = {"W": 1, "A": 2, "S": 4, "D": 8, "LSHIFT": 16, "SPACE": 32, "UP": 64, "DOWN": 128, "LEFT": 256, "RIGHT": 512}   # RTXH_KEY_*
+
+
+def camera_update(delta: float, keys, position, rotation):
+    """Camera::update's keyboard half (Camera.cpp:18-39); keys: iterable of names from KEYS.  Returns (position, rotation)."""
+    p, r = _f32(position).copy(), _f32(rotation).copy()
+    mask = 0
+    for k in keys:
+        mask |= KEYS[k]
+    assert lib().rtxh_camera_update(C.c_float(float(np.float32(delta))), mask, p.ctypes.data, r.ctypes.data) == 0
+    return p, r
 
 
 def camera_basis(width: int, height: int, fov: float, position, rotation) -> np.ndarray:

@@ -6,6 +6,7 @@
  * runs on the GPU and nothing here renders; the render path itself is librtx_hip.so.
  *
  *   rtxh_camera_basis        Camera::resize + Camera::update basis       Camera.cpp:5-16,44-47
+ *   rtxh_camera_update       Camera::update keyboard movement             Camera.cpp:18-39
  *   rtxh_instance_update     Mesh::update                                 Mesh.cpp:9-15
  *                            (Transform::calc_world_matrix Transform.h:13-43, AABB::transform
  *                             AABB.cpp:55-73, Matrix4::invert Matrix4.h:88-138)
@@ -81,6 +82,12 @@ int rtxh_blas_build_reference_bvh(const float * positions, int32_t triangle_coun
 int rtxh_blas_build_reference_sbvh(const float * positions, int32_t triangle_count,
                                    rtx_bvh_node * nodes_out, int32_t node_capacity, int32_t * node_count_out,
                                    int32_t * order_out, int32_t order_capacity, int32_t * order_count_out);
+
+/* Camera::update's input handling (Camera.cpp:18-39): keys = OR of RTXH_KEY_* held during this frame; position / rotation are
+ * updated in place (follow with rtxh_camera_basis for the view pyramid, Camera.cpp:44-47).                                      */
+enum { RTXH_KEY_W = 1, RTXH_KEY_A = 2, RTXH_KEY_S = 4, RTXH_KEY_D = 8, RTXH_KEY_LSHIFT = 16, RTXH_KEY_SPACE = 32,
+       RTXH_KEY_UP = 64, RTXH_KEY_DOWN = 128, RTXH_KEY_LEFT = 256, RTXH_KEY_RIGHT = 512 };
+int rtxh_camera_update(float delta, uint32_t keys, float position[3], float rotation[4]);
 
 /* Scene::update in two calls (Scene.cpp:139-171).  rtxh_scene_dynamic_animate is the animation SCENE_DYNAMIC hard-codes (:141-155,
  * instances 0..5; *time is the function-static `time`); rtxh_scene_update is the common tail (:166-170): Mesh::update for every

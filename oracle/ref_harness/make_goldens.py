@@ -129,7 +129,8 @@ def main():
     # BVH_VISUALIZE_HEATMAP builds (Config.h:23, Raytracer.cpp:97-102): same scenes, pixels = BLAS traversal steps
     golden("monkey_small", "monkey_small", "s0_m1_b3_t2_heat", keep_scene=False, tag="heat")
     golden("materials", "materials", "s0_m1_b3_t2_heat", extra=mat_extra[:2], keep_scene=False, tag="heat")
-    if "--heat-only" in sys.argv:
+    golden("camera_keys", "camera_keys", "s0_m1_b3_t2")      # Camera::update with keys held, through the harness's `keys` command
+    if "--heat-only" in sys.argv or "--extras-only" in sys.argv:
         return
 
     golden("cube", "cube", "s0_m1_b0_t2")

@@ -52,9 +52,9 @@ Window::Window(int width, int height, const char * title) :
 }
 Window::~Window() { delete [] frame_buffer; }
 
-// Scene::update polls the keyboard (Scene.cpp:165).  Headless: no key is ever down.
+// Scene::update polls the keyboard (Scene.cpp:165).  Headless: no key is down unless the script holds some (`keys ...`).
 static Uint8 no_keys[SDL_NUM_SCANCODES];
-extern "C" const Uint8 * SDL_GetKeyboardState(int * numkeys) { if (numkeys) *numkeys = SDL_NUM_SCANCODES; return no_keys; }
+extern "C" const Uint8 * SDL_GetKeyboardState(int * numkeys) { if (numkeys) *numkeys = SDL_NUM_SCANCODES; return no_keys; }   // script command `keys` presses some
 
 // ---- chunk writer ------------------------------------------------------------------------------
 struct ChunkWriter {
@@ -132,6 +132,15 @@ int main(int argc, char ** argv) {
 			else if (w[0] == "bounces") { bounces = atoi(w[1].c_str()); }
 			else if (w[0] == "frames")  { frames = atoi(w[1].c_str()); delta = F(2); }
 			else if (w[0] == "reps")    { render_reps = atoi(w[1].c_str()); }
+			else if (w[0] == "keys")    {   // held down during every Scene::update (Camera::update, Camera.cpp:18-48)
+				for (size_t k = 1; k < w.size(); k++) {
+					int sc = w[k] == "W" ? SDL_SCANCODE_W : w[k] == "A" ? SDL_SCANCODE_A : w[k] == "S" ? SDL_SCANCODE_S : w[k] == "D" ? SDL_SCANCODE_D :
+					         w[k] == "LSHIFT" ? SDL_SCANCODE_LSHIFT : w[k] == "SPACE" ? SDL_SCANCODE_SPACE : w[k] == "UP" ? SDL_SCANCODE_UP :
+					         w[k] == "DOWN" ? SDL_SCANCODE_DOWN : w[k] == "LEFT" ? SDL_SCANCODE_LEFT : w[k] == "RIGHT" ? SDL_SCANCODE_RIGHT : -1;
+					if (sc < 0) { fprintf(stderr, "unknown key %s\n", w[k].c_str()); return 2; }
+					no_keys[sc] = 1;
+				}
+			}
 			else if (w[0] == "base")    { keep_base = (w[1] == "keep"); }
 			else if (w[0] == "drop_base_meshes") { drop_base_meshes = true; }
 			else if (w[0] == "camera")  { have_camera = true; cam_pos = Vector3(F(1), F(2), F(3)); cam_rot = Quaternion(F(4), F(5), F(6), F(7)); }

@@ -106,3 +106,27 @@ def test_reference_bvh_cache_files_load_unchanged(mesh, golden, blas_index, tmp_
     host.save_bvh_cache(str(tmp_path / "x.bvh"), b)
     c = host.load_bvh_cache(str(tmp_path / "x.bvh"), ref.material_offset)
     assert c.nodes.tobytes() == b.nodes.tobytes() and c.tri_hot.tobytes() == b.tri_hot.tobytes() and c.tri_cold.tobytes() == b.tri_cold.tobytes()
+
+
+def test_camera_update_with_keys_matches_the_reference():
+    """Camera::update (Camera.cpp:18-48) with W, D, SPACE, LEFT, UP held for 4 updates of 0.02 s: the camera the REAL reference ended
+    up with (golden `camera_keys`, made through the harness's `keys` command) vs rtxh_camera_update + rtxh_camera_basis."""
+    sc, g = util.load_golden("camera_keys")
+    pos, rot = np.array([0.4, 0.2, -3.0], np.float32), host.axis_angle((0, 1, 0), 0.2)
+    for _ in range(4):
+        pos, rot = host.camera_update(0.02, ["W", "D", "SPACE", "LEFT", "UP"], pos, rot)
+    fov = float(np.float32(110.0) * np.float32(3.14159265359) * np.float32(0.00555555555))
+    cam = host.camera_basis(sc.width, sc.height, fov, pos, rot)
+    assert cam.tobytes() == sc.camera.tobytes()
+    still_p, still_r = host.camera_update(0.02, [], pos, rot)                      # no key: nothing moves
+    assert still_p.tobytes() == pos.tobytes() and still_r.tobytes() == rot.tobytes()
+    a = host.camera_update(0.02, ["W", "S"], pos, rot)[0]                          # opposite keys do not cancel exactly in fp32 ...
+    b = (pos + (host_forward(rot) * np.float32(10.0)) * np.float32(0.02)) - (host_forward(rot) * np.float32(10.0)) * np.float32(0.02)
+    assert a.tobytes() == b.astype(np.float32).tobytes()                           # ... they are applied one after the other, like the reference
+
+
+def host_forward(rot):
+    """rotation * (0, 0, 1) through the library (camera basis of a 2x2 view is overkill: use the instance matrix)."""
+    inst, _, _ = host.instance_update((0, 0, 0), rot, (-1, -1, -1), (1, 1, 1), 0)
+    w = inst["world"][0]                                                            # cells[i + 4 j]: third column = image of z
+    return np.array([w[2], w[6], w[10]], np.float32)

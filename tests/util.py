@@ -21,6 +21,7 @@ GOLDENS = {
     # BVH_VISUALIZE_HEATMAP builds of the reference (Config.h:23, Raytracer.cpp:97-102) on the same two scenes
     "monkey_small_heat": ("monkey_small", "heat", {"heatmap": 1}),
     "materials_heat": ("materials", "heat", {"heatmap": 1, "mip_filter": 1, "texture_mode": 2}),
+    "camera_keys": ("camera_keys", None, {}),
     "dynamic": ("dynamic", None, {}),
     "tori16": ("tori16", None, {}),
     "tori16_f1": ("tori16_f1", None, {}),
