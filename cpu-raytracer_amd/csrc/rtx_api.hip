@@ -60,6 +60,7 @@ struct rtx_ctx {
     size_t slots_alloc = 0, shadow_alloc = 0;
     DevBuf d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma;
     int trace_blocks_closest = 0, trace_blocks_any = 0, trace_blocks_count = 0;
+    bool merge_any = true;               // one-stream mode: ONE shadow-ray launch for all levels after the last shade (RTX_SERIAL_MERGE_ANY=0: one per level)
 
     rtx_stats stats_acc; rtx_work_counters work_acc; uint32_t err_flags_acc = 0;
     bool stats_pending = false;
@@ -160,6 +161,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     hipMemset(c->d_fb_packed.p, 0, px * 4);
 
     int bpc = 0;
+    if (const char * e = getenv("RTX_SERIAL_MERGE_ANY")) c->merge_any = atoi(e) != 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<false>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_closest = c->n_cu * (bpc > 0 ? bpc : 2);
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<true>, RTX_TRACE_BLOCK, 0);
@@ -436,6 +438,7 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
         // three of the per-launch tails (a persistent trace launch has a ~0.17 ms floor set by its slowest rays).
         const bool overlap = !count_work && !simple && sc.light_count > 0 && !c->serial;
         if (overlap && !c->any_stream) HIP_OK(c, hipStreamCreateWithFlags(&c->any_stream, hipStreamNonBlocking));
+        const bool merged = !overlap && !count_work && !simple && c->merge_any;
         if (sc.heatmap) {
             // BVH_VISUALIZE_HEATMAP: bounce() returns right after the primary ray's trace (Raytracer.cpp:97-102), so a frame is one
             // closest-hit pass in reference pop order (the plain kernel counts the steps) and one colouring pass
@@ -470,6 +473,11 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
                     launch_timed(c, "k_trace_any", c->any_stream, [&] {
                         hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 1, levels - 1); });
                 }
+            } else if (merged) {
+                // shadow rays only feed k_resolve: all levels' shadow rays are traced by ONE launch after the last shade (three fewer
+                // persistent-launch tails per frame)
+                if (level == levels - 1) launch_timed(c, "k_trace_any", c->stream, [&] {
+                    hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, 0, levels - 1); });
             } else launch_timed(c, "k_trace_any", c->stream, [&] {
                 if (count_work)   hipLaunchKernelGGL((k_trace<true, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (simple)  hipLaunchKernelGGL((k_trace<true, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
