@@ -377,10 +377,16 @@ static int alloc_queues(rtx_ctx * c, int batch_tiles) {
     return rc;
 }
 
-__global__ void k_begin_batch(DevCounters * ctr, uint32_t primary_slots, uint32_t closest_threads, uint32_t any_threads) {
-    // zero everything except the accumulating stats / work counters and the error flags; the dynamic-fetch heads start
-    // behind the statically assigned first round (one ray per resident thread)
+__global__ void k_begin_batch(DevCounters * ctr, uint32_t primary_slots, uint32_t closest_threads, uint32_t any_threads, int first_batch) {
+    // the first batch of a render call zeroes the whole counter block (stats of this call, WorkerThread.cpp:120) — done here rather than
+    // with hipMemsetAsync, whose blit serialises the streams of different contexts against each other; every batch then resets the
+    // queue state: the dynamic-fetch heads start behind the statically assigned first round (one ray per resident thread)
     const int i = threadIdx.x;
+    if (first_batch) {
+        uint32_t * w = reinterpret_cast<uint32_t *>(ctr);
+        for (int k = i; k < (int)(sizeof(DevCounters) / 4); k += blockDim.x) w[k] = 0u;
+        __syncthreads();
+    }
     if (i <= RTX_MAX_LEVELS) { ctr->ray_count[i] = (i == 0) ? primary_slots : 0u; ctr->lit_count[i] = 0u; ctr->fetch_closest[i] = closest_threads; ctr->fetch_any[i] = any_threads; }
 }
 
@@ -411,9 +417,8 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
     const bool cull = (flags & RTX_RENDER_CULL_DEAD_SHADOW_RAYS) != 0 && !simple && !count_work;
     c->serial = (flags & RTX_RENDER_SERIAL) != 0;
 
-    // stats of this call: reset accumulators (WorkerThread.cpp:120 zeroes them per frame)
-    HIP_OK(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(DevCounters), c->stream));
-    if (tile_count == 0) { c->stats_pending = true; return RTX_OK; }
+    // stats of this call are reset by the first k_begin_batch (WorkerThread.cpp:120 zeroes them per frame)
+    if (tile_count == 0) { hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, (DevCounters *)c->d_counters.p, 0u, 0u, 0u, 1); c->stats_pending = true; return RTX_OK; }
 
     int batch_tiles = 0;
     plan_batch(c, tile_count, batch_tiles);
@@ -431,7 +436,7 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
         const bool plain = count_work || simple || sc.heatmap;
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, q.counters, (uint32_t)q.primary_slots,
                            (uint32_t)((plain ? c->trace_blocks_count : c->trace_blocks_closest) * RTX_TRACE_BLOCK),
-                           (uint32_t)((plain ? c->trace_blocks_count : c->trace_blocks_any) * RTX_TRACE_BLOCK));
+                           (uint32_t)((plain ? c->trace_blocks_count : c->trace_blocks_any) * RTX_TRACE_BLOCK), done == 0 ? 1 : 0);
         // Main stream: closest(d) -> shade(d) for d = 0..D.  Shadow rays depend only on shade, so in the default (fast)
         // configuration they run on a second stream: any(level 0) starts after shade(0) and overlaps the deeper levels'
         // closest/shade kernels; the shadow rays of levels 1..D are traced by ONE more launch after shade(D).  This removes
