@@ -59,7 +59,7 @@ def random_scene(seed):
     return "\n".join(lines) + "\n", mip, tex_mode
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTX_FUZZ_SEEDS", "24"))))       # RTX_FUZZ_SEEDS=300 for a long soak
 def test_random_scene_gpu_equals_oracle(seed):
     import orc
     from pyrtx import api
