@@ -264,6 +264,7 @@ struct rtxh_tlas {
 namespace {
 struct TlasBuild {        // BVHBuilders::build_bvh<PrimitiveType>: used for Mesh instances (TLAS) and for triangles (reference BLAS)
     const float * pos; const float * aabb; rtxh_tlas * t; rtx_bvh_node * nodes; int node_index;
+    bool degenerate = false;     // NaN keys: the three sorted lists stop agreeing about who is left of the split (the reference overruns `temp` there)
     Box prim_box(int i) const { Box b; b.mn = mk(aabb[6 * i], aabb[6 * i + 1], aabb[6 * i + 2]); b.mx = mk(aabb[6 * i + 3], aabb[6 * i + 4], aabb[6 * i + 5]); return b; }
     float p(int i, int d) const { return pos[3 * i + d]; }
 
@@ -291,6 +292,7 @@ struct TlasBuild {        // BVHBuilders::build_bvh<PrimitiveType>: used for Mes
             }
         }
         float parent_cost = surface_area(b) * float(count);
+        if (min_index < 0) { degenerate = true; node.left_or_first = first; node.count = count; return; }   // every cost NaN: nothing to split on
         if (min_cost >= parent_cost) { node.left_or_first = first; node.count = count; return; }
 
         // split_indices: keep the other two lists consistent with the chosen split
@@ -308,8 +310,10 @@ struct TlasBuild {        // BVHBuilders::build_bvh<PrimitiveType>: used for Mes
                         j--;
                     }
                 }
-                if (goes_left) t->temp[l++] = prim; else t->temp[r++] = prim;
+                if (goes_left) { if (l >= min_index - first) { degenerate = true; break; } t->temp[l++] = prim; }
+                else           { if (r >= count)             { degenerate = true; break; } t->temp[r++] = prim; }
             }
+            if (degenerate) { node.left_or_first = first; node.count = count; return; }
             memcpy(&t->idx[d][first], t->temp.data(), sizeof(int) * count);
         }
         node.count = (min_dim + 1) << 30;
@@ -342,7 +346,7 @@ extern "C" int rtxh_tlas_build(rtxh_tlas * t, const float * positions, const flo
     b.build(0, 0, n);
     memcpy(indices_out, t->idx[0].data(), sizeof(int) * n);
     *node_count_out = b.node_index;
-    return RTX_OK;
+    return b.degenerate ? RTX_ERR_STATE : RTX_OK;
 }
 
 // The reference's non-spatial BLAS build (BottomLevelBVH::build_bvh, BottomLevelBVH.cpp:72-106): the same generic builder

@@ -68,7 +68,8 @@ struct Huffman {
     }
 };
 
-bool inflate_zlib(const uint8_t * data, size_t len, Bytes & out, bool has_header) {
+bool inflate_zlib(const uint8_t * data, size_t len, Bytes & out, bool has_header, size_t max_out) {
+    // max_out: the caller knows how many bytes it can use; decoding stops there (a few IDAT bytes must not inflate to gigabytes)
     static const uint16_t LEN_BASE[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
     static const uint8_t LEN_EXTRA[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
     static const uint16_t DIST_BASE[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
@@ -90,6 +91,7 @@ bool inflate_zlib(const uint8_t * data, size_t len, Bytes & out, bool has_header
             if ((n ^ 0xffffu) != nn || br.pos + n > len) return false;
             out.insert(out.end(), data + br.pos, data + br.pos + n);
             br.pos += n;
+            if (out.size() >= max_out) return true;
         } else if (type == 1 || type == 2) {
             Huffman lit, dist;
             uint8_t lengths[320];
@@ -128,7 +130,7 @@ bool inflate_zlib(const uint8_t * data, size_t len, Bytes & out, bool has_header
             for (;;) {
                 int s = lit.decode(br);
                 if (s < 0 || br.bad) return false;
-                if (s < 256) out.push_back((uint8_t)s);
+                if (s < 256) { out.push_back((uint8_t)s); if (out.size() >= max_out) return true; }
                 else if (s == 256) break;
                 else {
                     s -= 257;
@@ -140,6 +142,7 @@ bool inflate_zlib(const uint8_t * data, size_t len, Bytes & out, bool has_header
                     if (distance > out.size()) return false;
                     size_t from = out.size() - distance;
                     for (int k = 0; k < length; k++) out.push_back(out[from + k]);
+                    if (out.size() >= max_out) return true;
                 }
             }
         } else return false;
@@ -238,16 +241,22 @@ int png_decode(const Bytes & f, int32_t * w_out, int32_t * h_out, Bytes & rgba) 
         pos += 12 + (size_t)len;
     }
     if (idat.empty()) return RTX_ERR_INVALID_ARG;
-    Bytes raw;
-    raw.reserve(((size_t)w * 8 + 1) * h);
-    if (!inflate_zlib(idat.data(), idat.size(), raw, !is_iphone)) return RTX_ERR_INVALID_ARG;
-
     const int channels = color == 3 ? 1 : ((color & 2) ? 3 : 1) + ((color & 4) ? 1 : 0);
+    static const int X0[7] = { 0, 4, 0, 2, 0, 1, 0 }, Y0[7] = { 0, 0, 4, 0, 2, 0, 1 }, DX[7] = { 8, 8, 4, 4, 2, 2, 1 }, DY[7] = { 8, 8, 8, 4, 4, 2, 2 };
+    size_t expected = 0;                                                                          // filtered bytes the image needs
+    if (!interlace) expected = ((((size_t)w * channels * depth + 7) / 8) + 1) * h;
+    else for (int p = 0; p < 7; p++) {
+        const long pw = ((long)w - X0[p] + DX[p] - 1) / DX[p], ph = ((long)h - Y0[p] + DY[p] - 1) / DY[p];
+        if (pw > 0 && ph > 0) expected += ((((size_t)pw * channels * depth + 7) / 8) + 1) * (size_t)ph;
+    }
+    Bytes raw;
+    if (!inflate_zlib(idat.data(), idat.size(), raw, !is_iphone, expected)) return RTX_ERR_INVALID_ARG;
+    if (raw.size() < expected) return RTX_ERR_INVALID_ARG;                                        // checked before anything image-sized is allocated
+
     std::vector<uint16_t> img((size_t)w * h * channels);
     if (!interlace) {
         if (!png_unfilter(raw.data(), raw.size(), (int)w, (int)h, channels, depth, img)) return RTX_ERR_INVALID_ARG;
     } else {                                                                                     // Adam7
-        static const int X0[7] = { 0, 4, 0, 2, 0, 1, 0 }, Y0[7] = { 0, 0, 4, 0, 2, 0, 1 }, DX[7] = { 8, 8, 4, 4, 2, 2, 1 }, DY[7] = { 8, 8, 8, 4, 4, 2, 2 };
         size_t off = 0;
         std::vector<uint16_t> pass;
         for (int p = 0; p < 7; p++) {
@@ -337,6 +346,13 @@ int tga_decode(const Bytes & f, const TgaHeader & t, int32_t * w_out, int32_t * 
     auto rgb16_px = [&](uint8_t * o) { int px = get16(); o[0] = (uint8_t)((((px >> 10) & 31) * 255) / 31); o[1] = (uint8_t)((((px >> 5) & 31) * 255) / 31); o[2] = (uint8_t)(((px & 31) * 255) / 31); };
 
     const size_t px_count = (size_t)t.w * t.h;
+    if (px_count * comp > 0x7fffffffull) return RTX_ERR_LIMIT;                                   // stb_image's own limit (sizes must fit an int)
+    {   // a header can claim 65535 x 65535 pixels on a 20-byte file; stb_image would then read zeros past the end for minutes.  Large
+        // images must at least be long enough to hold their smallest possible encoding (RLE: one packet per 128 pixels).
+        const size_t remaining = f.size() > pos ? f.size() - pos : 0, unit = (size_t)(t.bpp + 7) / 8;
+        const size_t smallest = t.rle ? ((px_count + 127) / 128) * (1 + unit) : px_count * unit;
+        if (px_count > (1u << 22) && remaining < smallest) return RTX_ERR_INVALID_ARG;
+    }
     Bytes data(px_count * comp);
     Bytes pal;
     if (t.indexed) {

@@ -250,6 +250,10 @@ extern "C" int rtxh_obj_load(const char * path, rtxh_obj * out) {
 
     const int n = (int)tri_mat.size();
     if (n == 0) return RTX_ERR_INVALID_ARG;
+    // tinyobjloader does not range-check indices and the reference then reads past its arrays (OBJLoader.cpp:120-150); here a face that
+    // names a vertex / texcoord / normal the file does not have makes the file invalid
+    for (const VIdx & x : tri_idx)
+        if (x.v < 0 || (size_t)x.v >= v.size() / 3 || (x.vt >= 0 && (size_t)x.vt >= vt.size() / 2) || (x.vn >= 0 && (size_t)x.vn >= vn.size() / 3)) return RTX_ERR_INVALID_ARG;
     rtxh_mesh & m = out->mesh;
     m.triangle_count = n;
     m.positions = (float *)malloc(sizeof(float) * 9 * (size_t)n);

@@ -59,7 +59,7 @@ struct Sbvh {
     std::vector<B3> sweep_l, sweep_r;
     std::vector<unsigned char> to_left, to_right;
     rtx_bvh_node * nodes = nullptr;
-    int node_capacity = 0, node_index = 2;
+    int node_capacity = 0, node_index = 2, ref_capacity = 0;
     float inv_root_area = 0.0f;
     bool overflow = false, degenerate = false;
 
@@ -122,10 +122,11 @@ struct Sbvh {
                 if (v[0].v[d] > v[1].v[d]) std::swap(v[0], v[1]);
                 const float v_min = v[0].v[d], v_max = v[2].v[d];
 
-                int b_min = int(BINS * ((tb.mn[d] - lo) * inv_delta));
-                int b_max = int(BINS * ((tb.mx[d] - lo) * inv_delta));
-                b_min = b_min < 0 ? 0 : (b_min > BINS - 1 ? BINS - 1 : b_min);
-                b_max = b_max < 0 ? 0 : (b_max > BINS - 1 ? BINS - 1 : b_max);
+                // int(x) then Math::clamp(.., 0, BINS - 1) (BVHPartitions.h:205-209); out-of-range and NaN values are routed around the
+                // float -> int conversion (undefined there, INT_MIN on x86 -> bin 0): same bins, no undefined behaviour
+                auto bin_of = [&](float x) { return !(x > -1.0f) ? 0 : (x >= float(BINS) ? BINS - 1 : (int(x) > BINS - 1 ? BINS - 1 : (int(x) < 0 ? 0 : int(x)))); };
+                const int b_min = bin_of(BINS * ((tb.mn[d] - lo) * inv_delta));
+                const int b_max = bin_of(BINS * ((tb.mx[d] - lo) * inv_delta));
                 bins[b_min].entries++;
                 bins[b_max].exits++;
 
@@ -200,7 +201,7 @@ struct Sbvh {
     int build(int node_id, int first, int count, const B3 & box) {
         rtx_bvh_node & node = nodes[node_id];
         for (int d = 0; d < 3; d++) { node.aabb_min[d] = box.mn[d]; node.aabb_max[d] = box.mx[d]; }
-        if (count < 3) { node.left_or_first = first; node.count = count; return count; }
+        if (count < 3 || overflow) { node.left_or_first = first; node.count = count; return count; }   // (overflow: unwind, the result is discarded)
 
         if (node_index + 2 > node_capacity) { overflow = true; node.left_or_first = first; node.count = count; return count; }
         const int left = node_index;
@@ -303,6 +304,9 @@ struct Sbvh {
         }
 
         const int leaves_l = build(left, first, n_left, box_l);
+        // heavily overlapping input (e.g. thousands of coplanar triangles) multiplies references without bound; the reference overruns
+        // its 2n arrays there.  Stop as soon as the caller's capacity is exceeded instead of building a tree nobody can hold.
+        if (overflow || (size_t)first + leaves_l + n_right > (size_t)ref_capacity) { overflow = true; return leaves_l + n_right; }
         reserve_refs((size_t)first + leaves_l + n_right);
         for (int d = 0; d < 3; d++) memcpy(ref[d].data() + first + leaves_l, right_refs[d].data(), sizeof(int) * (size_t)n_right);
         for (int d = 0; d < 3; d++) std::vector<int>().swap(right_refs[d]);
@@ -335,7 +339,7 @@ extern "C" int rtxh_blas_build_reference_sbvh(const float * positions, int32_t n
     }
     s.sah.resize(n + 1);
     s.to_left.assign(n, 0); s.to_right.assign(n, 0);
-    s.nodes = nodes_out; s.node_capacity = node_capacity; s.node_index = 2;
+    s.nodes = nodes_out; s.node_capacity = node_capacity; s.node_index = 2; s.ref_capacity = order_capacity;
     memset(nodes_out, 0, sizeof(rtx_bvh_node) * (size_t)node_capacity);
 
     B3 root = b3_empty();                                                // BVHPartitions::calculate_bounds over the whole mesh

@@ -211,10 +211,11 @@ def build_blas(positions: np.ndarray, normals: np.ndarray, texcoords: np.ndarray
             oc = C.c_int32()
             rc = lib().rtxh_blas_build_reference_sbvh(pos.ctypes.data, n, nodes.ctypes.data, len(nodes), C.byref(nc),
                                                       order.ctypes.data, cap, C.byref(oc))
-            if rc != 4:   # RTX_ERR_LIMIT: more duplicated references than the reference's own 2n arrays hold
-                break
+            if rc != 4 or cap >= 32 * n:   # RTX_ERR_LIMIT: more duplicated references than the reference's own 2n arrays hold
+                break                          # (beyond 32n the input is pathological, e.g. piles of coplanar overlapping triangles: give up)
             cap *= 2
-        assert rc == 0, rc
+        if rc:
+            raise ValueError(f"rtxh_blas_build_reference_sbvh failed with status {rc}" + (" (reference explosion: try the plain BVH)" if rc == 4 else ""))
         order = order[:oc.value]
     else:
         nodes = np.zeros(2 * n, sio.BVH_NODE)

@@ -71,3 +71,40 @@ def test_scene_built_from_obj_renders_like_the_oracle():
     ref = orc.OracleScene(sc).render(threads=8)
     assert out["stats"] == ref["stats"] and out["stats"]["reflection"] > 0
     assert np.array_equal(out["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+
+
+def test_obj_loader_rejects_out_of_range_indices_and_survives_garbage(tmp_path):
+    """tinyobjloader does not range-check face indices (the reference then reads past its arrays); here such a file is an error.
+    Random damage to OBJ / MTL text must load or be rejected, never crash (the same loop ran clean under ASAN + UBSAN)."""
+    p = tmp_path / "bad.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7\n")
+    with pytest.raises(RuntimeError):
+        host.load_obj(str(p))
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nf 1/1 2/5 3/1\n")
+    with pytest.raises(RuntimeError):
+        host.load_obj(str(p))
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -1 -2 -3\n")                      # relative indices are fine
+    assert host.load_obj(str(p))[0].shape == (1, 3, 3)
+    rng = np.random.default_rng(9)
+    raw = open(os.path.join(D, "Concave.obj"), "rb").read()
+    mtl = open(os.path.join(D, "Concave.mtl"), "rb").read()
+    loaded = rejected = 0
+    for k in range(60):
+        b, m = bytearray(raw), bytearray(mtl)
+        tgt = b if k % 3 else m
+        if k % 4 == 0:
+            for _ in range(int(rng.integers(1, 8))):
+                tgt[int(rng.integers(0, len(tgt)))] = int(rng.integers(0, 256))
+        elif k % 4 == 1:
+            del tgt[int(rng.integers(0, len(tgt))):]
+        elif k % 4 == 2:
+            i = int(rng.integers(0, len(tgt))); tgt[i:i] = b"f 1/2/3 -5/-6/-7 99999999/1/1 4//4\nv 1e999 -1e-999 nan\nvt\nvn 1\nusemtl nothing\nmtllib\n"
+        else:
+            i = int(rng.integers(0, len(tgt))); tgt[i:i] = bytes(rng.integers(0, 256, 30).astype(np.uint8))
+        (tmp_path / "m.obj").write_bytes(bytes(b).replace(b"Concave.mtl", b"m.mtl")); (tmp_path / "m.mtl").write_bytes(bytes(m))
+        try:
+            pos, nrm, uv, mid, mats, names = host.load_obj(str(tmp_path / "m.obj")); loaded += 1
+            assert len(pos) == len(mid) and mid.max() < len(mats)
+        except RuntimeError:
+            rejected += 1
+    assert loaded > 10
