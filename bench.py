@@ -49,6 +49,66 @@ def _group(times):
     return g
 
 
+def cpu_quota():
+    """CPU share the container actually grants (cgroup v2 cpu.max / v1 cfs quota), in cores, or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            return None if q <= 0 else round(q / per, 2)
+        except Exception:
+            return None
+
+
+def reference_cpu_baseline(args, rays_per_frame, stats):
+    """The REAL reference (oracle/_ref/refdump_*, built from /root/reference in the build container; only the binary travels) on this
+    box's host cores: its own tile loop on a thread pool (WorkerThread.cpp:53-65), SIMD_LANE_SIZE 1, on the same mesh / lights / camera
+    (handed over as OBJ + MTL + TGA text, the way the reference loads scenes).  Returns None when the binary is absent or anything fails."""
+    import shutil, subprocess, tempfile
+    exe = os.path.join(REPO, "oracle", "_ref", "refdump_s0_m1_b3_t2")
+    if args.workload != "atrium" or not os.path.exists(exe):
+        return None
+    work = tempfile.mkdtemp(prefix="rtx_refbase_")
+    try:
+        from pyrtx import host, obj_export
+        data = os.path.join(work, "Data")
+        os.makedirs(os.path.join(data, "Sky_Probes")); os.makedirs(os.path.join(data, "sponza"))
+        host.synthetic_sky().tofile(os.path.join(data, "Sky_Probes", "rnl_probe.float"))
+        meshes = os.path.join(REPO, "tests", "golden", "meshes")              # SCENE_SPONZA's constructor opens three meshes before the script
+        for dst in ("sponza/sponza.obj", "Magnifier.obj", "Concave.obj"):     # replaces them (Scene.cpp:77-79): stage a small one under each name
+            shutil.copy(os.path.join(meshes, "Diamond.obj"), os.path.join(data, dst))
+        shutil.copy(os.path.join(meshes, "Diamond.mtl"), os.path.join(data, "sponza", "Diamond.mtl"))
+        shutil.copy(os.path.join(meshes, "Diamond.mtl"), os.path.join(data, "Diamond.mtl"))
+        seed = 0x5EED0003
+        pos, nrm, uv, mid, nmat = host.atrium_mesh(seed, args.detail)
+        obj_export.write_obj(os.path.join(data, "atrium"), "atrium", pos, nrm, uv, mid, host.atrium_materials(nmat), host.procedural_texture_images(seed))
+        cam, pt, sp, dr = host.ATRIUM_CAMERA, host.ATRIUM_POINT, host.ATRIUM_SPOT, host.ATRIUM_DIR
+        with open(os.path.join(work, "scene.txt"), "w") as f:
+            f.write(f"size {args.width} {args.height}\nbounces 3\nmesh ./Data/atrium/atrium.obj 0 0 0\n")
+            f.write("point %g %g %g %g %g %g\n" % (*pt[0], *pt[1]))
+            f.write("spot %g %g %g %g %g %g %.9g %.9g %.9g %g %g\n" % (*sp[0], *sp[1], *sp[2], sp[3], sp[4]))
+            f.write("dir %g %g %g %.9g %.9g %.9g\n" % (*dr[0], *dr[1]))
+            f.write("camera_axis_angle %g %g %g %g %g %g %.9g\n" % (*cam[0], *cam[1][0], cam[1][1]))
+        cores = os.cpu_count() or 1
+        out = os.path.join(work, "out")
+        subprocess.run([exe, "scene.txt", out, "--threads", str(cores), "--frames", "5", "--timing-only"], cwd=work, check=True, timeout=600,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t = json.load(open(os.path.join(out, "timing.json")))
+        ref_stats = {"primary": t["primary"], "shadow": t["shadow"], "reflection": t["reflection"], "refraction": t["refraction"]}
+        ms = t["render_ms_threads_best"]
+        return {"value": round(sum(ref_stats.values()) / (ms * 1e-3) * 1e-6, 3), "unit": "Mrays/s", "cores": cores, "kind": "reference",
+                "sample": f"best of 5 full frames of the same workload by the real reference (clayne/CPU-Raytracer sources compiled with g++ -O2, SIMD_LANE_SIZE 1, its own SBVH), "
+                          f"its tile loop on {cores} threads; one thread: {t['render_tile_ms_1thread']:.0f} ms per frame",
+                "ms_per_frame": round(ms, 2), "ray_counts_equal_to_gpu": ref_stats == stats, "container_cpu_quota_cores": cpu_quota()}
+    except Exception as e:                                                  # never let the baseline break the benchmark line
+        sys.stderr.write(f"reference baseline skipped: {e!r}\n")
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +121,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget (0 disables)")
+    ap.add_argument("--no-reference-baseline", action="store_true", help="CPU baseline from the oracle port only (skip the run of oracle/_ref's real reference)")
     ap.add_argument("--simple-trace", action="store_true", help="A/B: plain pop-and-test traversal kernels")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="contexts rendering consecutive frames concurrently (1 = one frame at a time)")
     ap.add_argument("--simulate-ranks", type=int, default=0, help="single-GPU rehearsal: render only the tile shard rank 0 of N would own (no gather)")
@@ -276,9 +337,13 @@ def main():
                 t_cpu += time.perf_counter() - t
                 frames += 1
             cpu_rays = sum(ref["stats"].values())
-            out["cpu_baseline"] = {"value": round(cpu_rays * frames / t_cpu * 1e-6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                                   "sample": f"{frames} full frame(s) of the same workload, oracle/rt_oracle.c (scalar lane-1 restatement), {cores} threads",
-                                   "ms_per_frame": round(1000.0 * t_cpu / frames, 2)}
+            port = {"value": round(cpu_rays * frames / t_cpu * 1e-6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                    "sample": f"{frames} full frame(s) of the same workload, oracle/rt_oracle.c (scalar lane-1 restatement), {cores} threads",
+                    "ms_per_frame": round(1000.0 * t_cpu / frames, 2), "container_cpu_quota_cores": cpu_quota()}
+            real = None if args.no_reference_baseline else reference_cpu_baseline(args, tot[4], stats)
+            out["cpu_baseline"] = real or port                              # the real reference when its binary is here, else the port
+            if real:
+                out["cpu_baseline_port"] = port
             rgb = fb_rgb.cpu().numpy().reshape(H, W, 3)
             d = np.abs(rgb.astype(np.float64) - ref["rgb"].astype(np.float64))
             out["parity"] = {"max_abs_rgb_vs_oracle": float(np.nanmax(d)), "pixels_differing": int((d.max(axis=-1) > 0).sum()),

@@ -25,6 +25,8 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <thread>
+#include <atomic>
 #include <sstream>
 #include <fstream>
 #include <map>
@@ -104,6 +106,12 @@ static int resolve_material(const std::string & target) {
 int main(int argc, char ** argv) {
 	if (argc < 3) { fprintf(stderr, "usage: refdump <script> <outdir> [--threads N]\n  (cwd must contain ./Data as the reference expects, Util.h:6)\n"); return 2; }
 	std::string script = argv[1], outdir = argv[2];
+	int mt_threads = 0, mt_frames = 3; bool timing_only = false;           // --threads N [--frames K] [--timing-only]: the reference's worker pool, timed
+	for (int a = 3; a < argc; a++) {
+		if (!strcmp(argv[a], "--threads") && a + 1 < argc) mt_threads = atoi(argv[++a]);
+		else if (!strcmp(argv[a], "--frames") && a + 1 < argc) mt_frames = atoi(argv[++a]);
+		else if (!strcmp(argv[a], "--timing-only")) timing_only = true;
+	}
 	std::filesystem::create_directories(outdir);
 
 	int W = 256, H = 256, bounces = NUMBER_OF_BOUNCES, frames = 1; float delta = 0.0f;
@@ -252,6 +260,45 @@ int main(int argc, char ** argv) {
 			auto t1 = std::chrono::high_resolution_clock::now();
 			best_ms = std::min(best_ms, std::chrono::duration<double, std::milli>(t1 - t0).count());
 		}
+	}
+
+	// ---- pass 1b: the same loop on N threads pulling tiles from an atomic counter, exactly WorkerThread.cpp:53-65 (Win32 threads
+	//      and events replaced by std::thread; each thread owns its PerformanceStats, :110).  Timing only; pixels are identical.
+	double mt_best_ms = -1.0; PerformanceStats stats_mt = { 0, 0, 0, 0 };
+	if (tiles_valid && mt_threads > 0) {
+		mt_best_ms = 1e30;
+		for (int rep = 0; rep < mt_frames; rep++) {
+			std::atomic<int> remaining(window.tile_count_x * window.tile_count_y);
+			std::vector<PerformanceStats> per(mt_threads, PerformanceStats{ 0, 0, 0, 0 });
+			std::vector<std::thread> pool;
+			auto t0 = std::chrono::high_resolution_clock::now();
+			for (int t = 0; t < mt_threads; t++) pool.emplace_back([&, t] {
+				for (;;) {
+					int task = remaining.fetch_sub(1) - 1;               // _InterlockedDecrement, WorkerThread.cpp:54
+					if (task < 0) break;
+					int x = (task % window.tile_count_x) * window.tile_width;
+					int y = (task / window.tile_count_x) * window.tile_height;
+					int tw = x + window.tile_width  < window.width  ? window.tile_width  : window.width  - x;
+					int th = y + window.tile_height < window.height ? window.tile_height : window.height - y;
+					raytracer.render_tile(window, x, y, tw, th, per[t]);
+				}
+			});
+			for (auto & th : pool) th.join();
+			auto t1 = std::chrono::high_resolution_clock::now();
+			mt_best_ms = std::min(mt_best_ms, std::chrono::duration<double, std::milli>(t1 - t0).count());
+			stats_mt = { 0, 0, 0, 0 };
+			for (auto & p : per) { stats_mt.num_primary_rays += p.num_primary_rays; stats_mt.num_shadow_rays += p.num_shadow_rays; stats_mt.num_reflection_rays += p.num_reflection_rays; stats_mt.num_refraction_rays += p.num_refraction_rays; }
+		}
+	}
+	if (timing_only) {
+		FILE * f = fopen((outdir + "/timing.json").c_str(), "w");
+		fprintf(f, "{\"width\": %d, \"height\": %d, \"threads\": %d, \"frames\": %d, \"render_ms_threads_best\": %.3f, \"render_tile_ms_1thread\": %.3f,\n"
+		           " \"primary\": %lld, \"shadow\": %lld, \"reflection\": %lld, \"refraction\": %lld, \"simd_lane_size\": %d}\n",
+		        W, H, mt_threads, mt_frames, mt_best_ms, tiles_valid ? best_ms : -1.0,
+		        (long long)stats_tiles.num_primary_rays, (long long)stats_tiles.num_shadow_rays, (long long)stats_tiles.num_reflection_rays, (long long)stats_tiles.num_refraction_rays, SIMD_LANE_SIZE);
+		fclose(f);
+		if (mt_threads > 0 && (stats_mt.num_primary_rays != stats_tiles.num_primary_rays || stats_mt.num_shadow_rays != stats_tiles.num_shadow_rays)) { fprintf(stderr, "thread pool ray counts differ\n"); return 3; }
+		return 0;
 	}
 
 	// ---- pass 2: bounce() per pixel for fp32 colours ----------------------------------------------
