@@ -253,8 +253,10 @@ int rtx_set_frame(rtx_ctx * ctx, const rtx_frame * frame);
 enum {
     RTX_RENDER_COUNT_WORK = 1,         /* also fill rtx_work_counters (instrumented kernels) */
     RTX_RENDER_SIMPLE_TRACE = 2,       /* use the plain pop-and-test traversal kernels (A/B reference for the pair-fetch kernels) */
-    RTX_RENDER_SERIAL = 8,             /* launch every kernel on one stream, one shadow-ray launch per level (no overlap of the
-                                          shadow-ray kernels with the next levels): for per-kernel timings                       */
+    RTX_RENDER_SERIAL = 8,             /* launch every kernel on ONE stream: closest-hit + shade per level, then a single shadow-ray
+                                          launch for all levels, then resolve.  Use when several contexts render consecutive
+                                          frames concurrently (one stream each); the default (two streams, shadow rays of level 0
+                                          overlapping the deeper levels) gives the lowest latency for one frame at a time          */
     RTX_RENDER_CULL_DEAD_SHADOW_RAYS = 4 /* count, but do not traverse, shadow rays whose unshadowed light contribution is exactly 0
                                           (N.L <= 0 or outside a spot cone): the pixel cannot depend on them.  Frames and
                                           rtx_stats are bit-identical with and without this flag.                                   */
