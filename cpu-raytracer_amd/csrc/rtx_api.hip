@@ -50,6 +50,8 @@ struct rtx_ctx {
     std::vector<DevTexture> h_tex;
     std::vector<void *> tex_allocs;
     int material_count = 0, sky_size = 0;
+    // host copies for validate_references(): every id a kernel will follow is checked on the host before anything is launched
+    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material; std::vector<int> frame_primitive_materials; bool refs_dirty = true;
 
     DevBuf f_tlas, f_tlas_idx, f_inst, f_sph, f_pln, f_pl, f_sl, f_dl;
     DevScene scene;
@@ -229,6 +231,10 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
     HIP_OK(c, hipMemcpy(dn, nd.data(), nd.size() * 16, hipMemcpyHostToDevice));
     HIP_OK(c, hipMemcpy(dt, th.data(), th.size() * 16, hipMemcpyHostToDevice));
     if (triangle_count) HIP_OK(c, hipMemcpy(dc, tri_cold, (size_t)triangle_count * sizeof(rtx_triangle_cold), hipMemcpyHostToDevice));
+    if (c->blas_max_local_material.size() <= (size_t)blas_id) c->blas_max_local_material.resize(blas_id + 1, -1);
+    int max_local = -1;
+    for (int i = 0; i < triangle_count; i++) { if (tri_cold[i].material_id < 0) return RTX_ERR_INVALID_ARG; if (tri_cold[i].material_id > max_local) max_local = tri_cold[i].material_id; }
+    c->blas_max_local_material[blas_id] = max_local; c->refs_dirty = true;
     DevBlas & B = c->h_blas[blas_id];
     B.nodes = (const float4 *)dn; B.tri_hot = (const float4 *)dt; B.tri_cold = (const rtx_triangle_cold *)dc;
     B.node_count = node_count; B.tri_count = triangle_count; B.material_offset = material_offset; B.pad = 0;
@@ -240,6 +246,7 @@ extern "C" int rtx_upload_materials(rtx_ctx * c, const rtx_material * materials,
     if (count > RTX_MAX_MATERIALS) return RTX_ERR_LIMIT;       // "Max Material limit reached!" Material.h:33-37
     hipSetDevice(c->cfg.device);
     c->material_count = count;
+    c->h_materials.assign(materials, materials + count); c->refs_dirty = true;
     return upload(c, c->d_materials, materials, (size_t)count * sizeof(rtx_material));
 }
 
@@ -258,6 +265,7 @@ extern "C" int rtx_upload_texture(rtx_ctx * c, int32_t texture_id, const rtx_tex
     HIP_OK(c, hipMemcpy(d, texels_rgb, (size_t)texel_count * 12, hipMemcpyHostToDevice));
     c->h_tex[texture_id].desc = *desc;
     c->h_tex[texture_id].texels = (const float *)d;
+    c->refs_dirty = true;
     return upload(c, c->d_textures, c->h_tex.data(), c->h_tex.size() * sizeof(DevTexture));
 }
 
@@ -329,7 +337,29 @@ extern "C" int rtx_set_frame(rtx_ctx * c, const rtx_frame * f) {
     s.spot_lights = (const rtx_spot_light *)c->f_sl.p; s.spot_light_count = f->spot_light_count;
     s.dir_lights = (const rtx_directional_light *)c->f_dl.p; s.dir_light_count = f->directional_light_count;
     s.light_count = f->point_light_count + f->spot_light_count + f->directional_light_count;
-    c->frame_set = true;
+    c->frame_primitive_materials.clear();
+    for (int i = 0; i < f->sphere_count; i++) c->frame_primitive_materials.push_back(f->spheres[i].material_id);
+    for (int i = 0; i < f->plane_count; i++) c->frame_primitive_materials.push_back(f->planes[i].material_id);
+    c->frame_set = true; c->refs_dirty = true;
+    return RTX_OK;
+}
+
+// Every index a kernel dereferences without a bounds check of its own — material ids of primitives and triangles, texture ids of
+// materials — is verified here, once after any upload / rtx_set_frame: a wrong id must become a status code, not a GPU memory fault.
+static int validate_references(rtx_ctx * c) {
+    if (!c->refs_dirty) return RTX_OK;
+    const int nm = c->material_count;
+    for (int id : c->frame_primitive_materials) if (id < 0 || id >= nm) { c->err = "sphere / plane material id outside the uploaded material table"; return RTX_ERR_STATE; }
+    for (size_t b = 0; b < c->h_blas.size(); b++) {
+        if (!c->h_blas[b].nodes) continue;
+        const int hi = b < c->blas_max_local_material.size() ? c->blas_max_local_material[b] : -1;
+        if (c->h_blas[b].material_offset < 0 || (hi >= 0 && (long long)c->h_blas[b].material_offset + hi >= nm)) { c->err = "BLAS material_offset + triangle material id outside the uploaded material table"; return RTX_ERR_STATE; }
+    }
+    for (size_t i = 0; i < c->h_materials.size(); i++) {
+        const int t = c->h_materials[i].texture_id;
+        if (t >= 0 && ((size_t)t >= c->h_tex.size() || !c->h_tex[t].texels)) { c->err = "material refers to a texture id that was never uploaded"; return RTX_ERR_STATE; }
+    }
+    c->refs_dirty = false;
     return RTX_OK;
 }
 
@@ -409,6 +439,7 @@ static void launch_timed(rtx_ctx * c, const char * name, hipStream_t stream, F &
 extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_stride, int32_t tile_count, uint32_t flags) {
     if (!c || first_tile < 0 || tile_stride < 1 || tile_count < 0) return RTX_ERR_INVALID_ARG;
     if (!c->frame_set) { c->err = "rtx_render_tiles before rtx_set_frame"; return RTX_ERR_STATE; }
+    if (int bad = validate_references(c)) return bad;
     const int tcx = (c->cfg.width + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE, tcy = (c->cfg.height + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE;
     if (tile_count > 0 && first_tile + (int64_t)(tile_count - 1) * tile_stride >= (int64_t)tcx * tcy) return RTX_ERR_INVALID_ARG;
     hipSetDevice(c->cfg.device);

@@ -35,7 +35,7 @@
 
 struct DevBlas {
     const float4 *            nodes;      // 2 x float4 per node: (min.xyz, left_or_first) (max.xyz, count)
-    const float4 *            tri_hot;    // 3 x float4 per triangle: (p0, -) (e1, -) (e2, -)
+    const float4 *            tri_hot;    // RTX_TRI_STRIDE x float4 per triangle: (p0, -) (e1, -) (e2, -) (padding)
     const rtx_triangle_cold * tri_cold;   // reference layout, 64 B
     int32_t node_count, tri_count, material_offset, pad;
 };

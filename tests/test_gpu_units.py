@@ -115,3 +115,26 @@ def test_stack_overflow_is_reported_not_silent(api):
     with pytest.raises(api.RtxError) as e:
         r.stats()
     assert e.value.code == 4
+
+
+def test_dangling_material_and_texture_ids_are_refused_before_launch(api):
+    """A material id past the table or a texture id never uploaded would make a kernel read out of bounds; the C ABI must answer
+    with RTX_ERR_STATE from rtx_render_tiles instead (the reference would index MaterialBuffer::materials blindly)."""
+    import copy
+    base, _ = util.load_golden("materials_aniso")
+    def attempt(mutate):
+        sc = copy.deepcopy(base)
+        mutate(sc)
+        r = api.Renderer(sc)
+        with pytest.raises(api.RtxError) as e:
+            r.render_async()
+        assert e.value.code == 5, e.value
+    def bad_sphere(sc): sc.spheres["material_id"][0] = len(sc.materials) + 3
+    def bad_plane(sc): sc.planes["material_id"][0] = -2
+    def bad_triangle(sc): sc.blas[0].tri_cold["material_id"][0] = 200
+    def bad_texture(sc): sc.materials["texture_id"][1] = 77
+    def short_table(sc): sc.materials = sc.materials[:2].copy()
+    for m in (bad_sphere, bad_plane, bad_triangle, bad_texture, short_table):
+        attempt(m)
+    ok = api.Renderer(copy.deepcopy(base)).render()                       # the untouched scene still renders
+    assert ok["stats"]["primary"] == base.width * base.height
