@@ -200,6 +200,25 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     return RTX_OK;
 }
 
+// Walks the nodes a traversal can reach from the root (abandoned child pairs and index 1 hold garbage in reference-built arrays and are
+// not looked at): every leaf range inside the primitive array, every child pair inside the node array, and no node reachable twice —
+// a cycle would keep a GPU traversal going for ever.
+static bool validate_tree(const rtx_bvh_node * nodes, int node_count, int64_t primitive_count) {
+    if (node_count < 1) return false;
+    std::vector<unsigned char> seen((size_t)node_count, 0);
+    std::vector<int> stack(1, 0);
+    while (!stack.empty()) {
+        const int i = stack.back(); stack.pop_back();
+        if (seen[i]) return false;
+        seen[i] = 1;
+        const int cnt = nodes[i].count & 0x3fffffff, f = nodes[i].left_or_first;
+        if (cnt > 0) { if (f < 0 || (int64_t)f + cnt > primitive_count) return false; }
+        else { if (f < 0 || f + 1 >= node_count) return false; stack.push_back(f); stack.push_back(f + 1); }
+    }
+    return true;
+}
+
+
 extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node * nodes, int32_t node_count,
                                const rtx_triangle_hot * tri_hot, const rtx_triangle_cold * tri_cold,
                                int32_t triangle_count, int32_t material_offset) {
@@ -207,12 +226,7 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
         return RTX_ERR_INVALID_ARG;
     hipSetDevice(c->cfg.device);
     // every leaf must address triangles inside the arrays, every inner node children inside the node array
-    for (int i = 0; i < node_count; i++) {
-        if (i == 1) continue;   // index 1 is never used (BVHBuilders.h:20-21)
-        const int cnt = nodes[i].count & 0x3fffffff, f = nodes[i].left_or_first;
-        if (cnt > 0) { if (f < 0 || (int64_t)f + cnt > triangle_count) return RTX_ERR_INVALID_ARG; }
-        else if (f < 0 || f + 1 >= node_count) return RTX_ERR_INVALID_ARG;
-    }
+    if (!validate_tree(nodes, node_count, triangle_count)) return RTX_ERR_INVALID_ARG;
     if ((size_t)blas_id >= c->h_blas.size()) { c->h_blas.resize(blas_id + 1); c->blas_allocs.resize(blas_id + 1); for (auto & b : c->h_blas) if (!b.nodes) memset(&b, 0, sizeof(b)); }
     for (void * p : c->blas_allocs[blas_id]) hipFree(p);
     c->blas_allocs[blas_id].clear();
@@ -289,12 +303,7 @@ extern "C" int rtx_set_frame(rtx_ctx * c, const rtx_frame * f) {
     if (f->instance_count >= (1 << 28) || f->sphere_count >= (1 << 28) || f->plane_count >= (1 << 28)) return RTX_ERR_LIMIT;
     hipSetDevice(c->cfg.device);
     // validate the TLAS against the instance table and the instances against the uploaded BLAS set
-    for (int i = 0; i < f->tlas_node_count; i++) {
-        if (i == 1) continue;
-        const int cnt = f->tlas_nodes[i].count & 0x3fffffff, first = f->tlas_nodes[i].left_or_first;
-        if (cnt > 0) { if (first < 0 || (int64_t)first + cnt > f->tlas_index_count) return RTX_ERR_INVALID_ARG; }
-        else if (first < 0 || first + 1 >= f->tlas_node_count) return RTX_ERR_INVALID_ARG;
-    }
+    if (f->tlas_node_count > 0 && !validate_tree(f->tlas_nodes, f->tlas_node_count, f->tlas_index_count)) return RTX_ERR_INVALID_ARG;
     for (int i = 0; i < f->tlas_index_count; i++) if (f->tlas_indices[i] < 0 || f->tlas_indices[i] >= f->instance_count) return RTX_ERR_INVALID_ARG;
     for (int i = 0; i < f->instance_count; i++) {
         const int b = f->instances[i].blas_id;

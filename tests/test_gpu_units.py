@@ -138,3 +138,21 @@ def test_dangling_material_and_texture_ids_are_refused_before_launch(api):
         attempt(m)
     ok = api.Renderer(copy.deepcopy(base)).render()                       # the untouched scene still renders
     assert ok["stats"]["primary"] == base.width * base.height
+
+
+def test_cyclic_node_arrays_are_refused(api):
+    """An inner node whose child pair does not lie behind it could send a traversal round in circles for ever (a hung GPU);
+    rtx_upload_blas / rtx_set_frame refuse such arrays — every builder of the reference allocates children after their parent."""
+    import copy
+    base, _ = util.load_golden("monkey_small")
+    sc = copy.deepcopy(base)
+    inner = [k for k in range(len(sc.blas[0].nodes)) if k != 1 and (int(sc.blas[0].nodes[k]["count"]) & 0x3fffffff) == 0]
+    sc.blas[0].nodes["left_or_first"][inner[5]] = 0                        # points back at the root pair
+    with pytest.raises(api.RtxError) as e:
+        api.Renderer(sc)
+    assert e.value.code == 1
+    sc = copy.deepcopy(base)
+    if len(sc.tlas_nodes) > 2 and (int(sc.tlas_nodes[0]["count"]) & 0x3fffffff) == 0:
+        sc.tlas_nodes["left_or_first"][0] = 0
+        with pytest.raises(api.RtxError):
+            api.Renderer(sc)
