@@ -10,9 +10,11 @@
 // bit-for-bit against the host libm in tests/test_libm.py (exhaustively for acosf and atanf).
 // The file also compiles for the host (plain C++) for exactly that test.
 //
-// expf / log2f feed continuous quantities (Beer attenuation, mip LOD): they are evaluated in fp64
-// and rounded once, i.e. correctly rounded fp32 except in ~1e-9 of cases; glibc's own expf/log2f
-// are within 0.502 ulp of that, so the two agree to <= 1 ulp (documented in DESIGN.md).
+// expf / log2f (Beer attenuation, mip LOD — the LOD is floored into a mip level, so it decides discretely too) are glibc 2.35's
+// own algorithms: the table-driven double-precision routines of ARM's optimized-routines (exp2f_data N = 32, log2f_data N = 16),
+// in the operation order AND fused-multiply-add pattern of the variant glibc selects on every FMA-capable x86-64 CPU
+// (`__expf_fma`, `__log2f_fma`, read off the disassembly of libm.so.6; tables and constants extracted from its .rodata).  fp64 +, *
+// and fma are correctly rounded on gfx950, so the results are the host's bit for bit (tests/test_libm.py, exhaustive sweep available).
 #pragma once
 #include <stdint.h>
 
@@ -179,7 +181,82 @@ RTX_LIBM_FN float rtx_atan2f(float y, float x) {
     }
 }
 
-#if defined(__HIPCC__)
-RTX_LIBM_FN float rtx_expf(float x)  { return (float)exp((double)x); }
-RTX_LIBM_FN float rtx_log2f(float x) { return (float)log2((double)x); }
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  #define RTX_FMA64(a, b, c) __builtin_fma((a), (b), (c))
+  #define RTX_U2D(u) __longlong_as_double((long long)(u))
+  #define RTX_D2U(d) ((uint64_t)__double_as_longlong(d))
+#else
+  static inline double rtx_u2d_host(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+  static inline uint64_t rtx_d2u_host(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+  #define RTX_FMA64(a, b, c) fma((a), (b), (c))
+  #define RTX_U2D(u) rtx_u2d_host(u)
+  #define RTX_D2U(d) rtx_d2u_host(d)
 #endif
+
+// glibc 2.35 __expf_fma (sysdeps/ieee754/flt-32/e_expf.c built with -mfma -mavx2).  T[i] = bits of 2^(i/32) with the exponent field
+// pre-adjusted so that adding (ki << 47) yields 2^(k/32) directly.
+RTX_LIBM_FN float rtx_expf(float x) {
+    const uint64_t T[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+        0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+        0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+        0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull };
+    const double SHIFT = 0x1.8p52, InvLn2N = 0x1.71547652b82fep+5, C0 = 0x1.c6af84b912394p-20, C1 = 0x1.ebfce50fac4f3p-13, C2 = 0x1.62e42ff0c52d6p-6;
+    const uint32_t ix = (uint32_t)RTX_F2I(x);
+    const uint32_t abstop = (ix >> 20) & 0x7ff;
+    if (abstop > 0x42a) {                                          // |x| >= 88 or so, inf, NaN
+        if (ix == 0xff800000u) return 0.0f;                        // exp(-inf)
+        if (abstop > 0x7f7) return x + x;                          // inf, NaN
+        if (x > 0x1.62e42ep6f) return RTX_I2F(0x7f800000);         // overflow: __math_oflowf
+        if (x < -0x1.9fe368p6f) return 0.0f;                       // underflow: __math_uflowf
+        if (x < -0x1.9d1d9ep6f) return RTX_I2F(0x00000001);        // __math_may_uflowf: 0x1.4p-75f squared rounds to the least subnormal
+    }
+    const double xd = (double)x;
+    double kd = RTX_FMA64(InvLn2N, xd, SHIFT);                     // z + SHIFT with z = InvLn2N * xd never rounded on its own
+    const uint64_t ki = RTX_D2U(kd);
+    kd = kd - SHIFT;
+    const double r = RTX_FMA64(InvLn2N, xd, -kd);                  // z - kd
+    const double s = RTX_U2D(T[ki & 31] + (ki << 47));
+    const double z = RTX_FMA64(r, C0, C1);
+    const double r2 = r * r;
+    double y = RTX_FMA64(r, C2, 1.0);
+    y = RTX_FMA64(z, r2, y);
+    y = y * s;
+    return (float)y;
+}
+
+// glibc 2.35 __log2f_fma (sysdeps/ieee754/flt-32/e_log2f.c built with -mfma -mavx2)
+RTX_LIBM_FN float rtx_log2f(float x) {
+    const double INVC[16] = { 0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0, 0x1.3c995b0b80385p+0, 0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,
+                              0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0, 0x1.0953f419900a7p+0, 0x1p+0, 0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
+                              0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1, 0x1.767dcf5534862p-1 };
+    const double LOGC[16] = { -0x1.efec65b963019p-2, -0x1.b0b6832d4fca4p-2, -0x1.7418b0a1fb77bp-2, -0x1.39de91a6dcf7bp-2, -0x1.01d9bf3f2b631p-2, -0x1.97c1d1b3b7afp-3,
+                              -0x1.2f9e393af3c9fp-3, -0x1.960cbbf788d5cp-4, -0x1.a6f9db6475fcep-5, 0x0p+0, 0x1.338ca9f24f53dp-4, 0x1.476a9543891bap-3,
+                              0x1.e840b4ac4e4d2p-3, 0x1.40645f0c6651cp-2, 0x1.88e9c2c1b9ff8p-2, 0x1.ce0a44eb17bccp-2 };
+    const double A0 = -0x1.712b6f70a7e4dp-2, A1 = 0x1.ecabf496832ep-2, A2 = -0x1.715479ffae3dep-1, A3 = 0x1.715475f35c8b8p+0;
+    uint32_t ix = (uint32_t)RTX_F2I(x);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {           // x < 0x1p-126, inf or NaN
+        if (ix * 2u == 0u) return RTX_I2F((int32_t)0xff800000);    // log2(+-0) = -inf (__math_divzerof)
+        if (ix == 0x7f800000u) return x;                           // log2(inf) = inf
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return (x - x) / (x - x);   // negative or NaN: __math_invalidf
+        ix = (uint32_t)RTX_F2I(x * 0x1p23f);                       // subnormal: normalise
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int32_t)tmp >> 23;                              // arithmetic shift
+    const double z = (double)RTX_I2F((int32_t)iz);
+    const double r = RTX_FMA64(z, INVC[i], -1.0);
+    const double y0 = LOGC[i] + (double)k;
+    const double r2 = r * r;
+    double y = RTX_FMA64(A1, r, A2);
+    const double p = RTX_FMA64(r, A3, y0);
+    y = RTX_FMA64(A0, r2, y);
+    y = RTX_FMA64(y, r2, p);
+    return (float)y;
+}

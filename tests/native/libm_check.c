@@ -1,5 +1,5 @@
 /* Exhaustive / randomised bit-for-bit comparison of csrc/rtx_libm.h against the host libm.
- * usage: libm_check acosf|atanf [stride]   sweeps ALL 2^32 bit patterns with the given stride (default 1 = exhaustive)
+ * usage: libm_check acosf|atanf|expf|log2f [stride]   sweeps ALL 2^32 bit patterns with the given stride (default 1 = exhaustive)
  *        libm_check atan2f [count]        count pseudo-random argument pairs of four kinds
  * prints "<name> checked=N mismatches=M" */
 #include <stdio.h>
@@ -20,6 +20,8 @@ static void * run(void * p) {
     job_t * j = (job_t *)p; j->mism = 0;
     if (j->mode == 0) { for (uint64_t u = j->lo; u < j->hi; u += j->stride) { float x = fb((uint32_t)u); if (!same(rtx_acosf(x), acosf(x))) { if (!j->mism) j->first_bad[0] = (uint32_t)u; j->mism++; } } }
     if (j->mode == 1) { for (uint64_t u = j->lo; u < j->hi; u += j->stride) { float x = fb((uint32_t)u); if (!same(rtx_atanf(x), atanf(x))) { if (!j->mism) j->first_bad[0] = (uint32_t)u; j->mism++; } } }
+    if (j->mode == 3) { for (uint64_t u = j->lo; u < j->hi; u += j->stride) { float x = fb((uint32_t)u); if (!same(rtx_expf(x), expf(x))) { if (!j->mism) j->first_bad[0] = (uint32_t)u; j->mism++; } } }
+    if (j->mode == 4) { for (uint64_t u = j->lo; u < j->hi; u += j->stride) { float x = fb((uint32_t)u); if (!same(rtx_log2f(x), log2f(x))) { if (!j->mism) j->first_bad[0] = (uint32_t)u; j->mism++; } } }
     if (j->mode == 2) {
         uint64_t s = 0x9E3779B97F4A7C15ull * (j->lo + 1);
         for (uint64_t i = j->lo; i < j->hi; i++) {
@@ -40,7 +42,7 @@ static void * run(void * p) {
 
 int main(int argc, char ** argv) {
     if (argc < 2) return 2;
-    int mode = !strcmp(argv[1], "acosf") ? 0 : !strcmp(argv[1], "atanf") ? 1 : 2;
+    int mode = !strcmp(argv[1], "acosf") ? 0 : !strcmp(argv[1], "atanf") ? 1 : !strcmp(argv[1], "expf") ? 3 : !strcmp(argv[1], "log2f") ? 4 : 2;
     uint64_t total = mode == 2 ? (argc > 2 ? strtoull(argv[2], 0, 0) : 400000000ull) : (1ull << 32);
     uint64_t stride = (mode != 2 && argc > 2) ? strtoull(argv[2], 0, 0) : 1;
     if (stride < 1) stride = 1;

@@ -98,4 +98,5 @@ def test_assembled_scene_renders_the_reference_frame_on_the_gpu(name):
     out = r.render()
     c = util.compare_to_golden(out, g)
     assert c["stats_equal"] and c["nan_mismatch"] == 0 and c["packed_mismatch"] == 0, c
-    assert c["max_abs"] < 1e-4, c                                   # BASELINE.json north_star tolerance
+    assert c["max_abs"] < 1e-4, c                                   # BASELINE.json north_star tolerance ...
+    assert c["bit_exact"], c                                        # ... and in fact identical

@@ -109,6 +109,7 @@ def test_gpu_renders_rebuilt_frames(name, frames):
         out = r.render()
     cmp = util.compare_to_golden(out, g)
     assert cmp["stats_equal"] and cmp["max_abs"] < 1e-4 and cmp["packed_mismatch"] == 0, cmp
+    assert cmp["max_abs"] == 0.0, cmp
 
 
 @pytest.mark.parametrize("name,frames", [("dynamic", 3), ("tori16", 2), ("tori16_f1", 1)])

@@ -61,3 +61,9 @@ def compare_to_golden(out, g):
         "packed_mismatch": int((packed != g["packed"]).sum()),
         "stats_equal": [int(out["stats"][k]) for k in ("primary", "shadow", "reflection", "refraction")] == g["stats"].tolist(),
     }
+
+
+def bit_exact(a, b):
+    """fp32 arrays equal bit for bit; two NaNs count as equal whatever their sign / payload (x86 and gfx950 generate different default NaNs)."""
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
