@@ -53,3 +53,20 @@ def test_struct_sizes_match_the_reference_layouts():
     assert sio.BVH_NODE.itemsize == 32      # BVHNode, SURVEY.md §8
     assert sio.TRI_HOT.itemsize == 36       # TriangleHot
     assert sio.TRI_COLD.itemsize == 64      # TriangleCold
+
+
+def test_missing_extension_fails_loudly(tmp_path):
+    """No silent fallback: when librtx_hip.so cannot be found the product path raises; nothing under oracle/ is imported by it."""
+    import subprocess, sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['RTX_HIP_LIB'] = %r\n"
+            "from pyrtx import api\n"
+            "try:\n    api.load_library()\nexcept Exception as e:\n    print('RAISED', type(e).__name__); sys.exit(0)\nsys.exit(1)\n") % (
+        os.path.join(REPO, "cpu-raytracer_amd"), str(tmp_path / "nowhere" / "librtx_hip.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and "RAISED" in out.stdout, (out.stdout, out.stderr)
+    # and the product package never reaches for the checker
+    for root, _, files in os.walk(os.path.join(REPO, "cpu-raytracer_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert not re.search(r"^\s*(import orc|from orc )|#\s*include[^\n]*rt_oracle|liboracle\.so", text, re.M), os.path.join(root, f)
