@@ -322,7 +322,10 @@ def main():
                          "frac": None if achieved is None else round(achieved / 8000.0, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_frame / max(launches_per_frame, 1)),
                          "avg_launch_ms": None if dom not in kern else round(kern[dom]["avg_ms"], 5),
-                         "bytes_per_ray": round(bytes_frame / max(alg[dom][1], 1), 1)},
+                         "bytes_per_ray": round(bytes_frame / max(alg[dom][1], 1), 1),
+                         "note": "achieved = ALGORITHMIC bytes (reference struct sizes x nodes / triangles visited, counted on the GPU and equal to the oracle's "
+                                 "counters) / launch time; the scene is cache-resident, so the measured memory traffic (`traffic`, PMC) is a few per cent of it and "
+                                 "frac can reach 1: the kernel is bound by the CUs' divergent-gather rate, not by HBM (DESIGN.md 5, 9)"},
         }
         # ---- CPU baseline: the oracle (port of the reference's lane-1 path) on this box's host cores ------
         if world == 1 and args.cpu_seconds > 0:
