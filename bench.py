@@ -62,6 +62,13 @@ def cpu_quota():
             return None
 
 
+def baseline_threads():
+    """Threads for the CPU baselines: what the container may actually run in parallel (its CPU quota), not the host's core count."""
+    n = os.cpu_count() or 1
+    q = cpu_quota()
+    return max(1, min(n, int(q + 0.999))) if q else n
+
+
 def reference_cpu_baseline(args, rays_per_frame, stats):
     """The REAL reference (oracle/_ref/refdump_*, built from /root/reference in the build container; only the binary travels) on this
     box's host cores: its own tile loop on a thread pool (WorkerThread.cpp:53-65), SIMD_LANE_SIZE 1, on the same mesh / lights / camera
@@ -91,7 +98,7 @@ def reference_cpu_baseline(args, rays_per_frame, stats):
             f.write("spot %g %g %g %g %g %g %.9g %.9g %.9g %g %g\n" % (*sp[0], *sp[1], *sp[2], sp[3], sp[4]))
             f.write("dir %g %g %g %.9g %.9g %.9g\n" % (*dr[0], *dr[1]))
             f.write("camera_axis_angle %g %g %g %g %g %g %.9g\n" % (*cam[0], *cam[1][0], cam[1][1]))
-        cores = os.cpu_count() or 1
+        cores = baseline_threads()
         out = os.path.join(work, "out")
         subprocess.run([exe, "scene.txt", out, "--threads", str(cores), "--frames", "5", "--timing-only"], cwd=work, check=True, timeout=600,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -331,7 +338,7 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             sys.path.insert(0, os.path.join(REPO, "oracle"))
             import orc
-            cores = os.cpu_count() or 1
+            cores = baseline_threads()
             o = orc.OracleScene(sc)
             frames, t_cpu, ref = 0, 0.0, None
             while t_cpu < args.cpu_seconds and frames < 50:
