@@ -126,6 +126,12 @@ public:
         materials.push_back(m);
         return (int)materials.size() - 1;
     }
+    void load_sky(const std::string & path) {                   // Sky::Sky, Sky.cpp:8-26
+        float * tx = nullptr; int32_t n = 0;
+        check(rtxh_sky_load(path.c_str(), &tx, &n), ("Sky::Sky " + path).c_str());
+        sky.assign(tx, tx + (size_t)n * n * 3); sky_size = n;
+        rtxh_texture_free(tx);
+    }
     int load_texture(const std::string & path) {                // Texture::load, Texture.cpp:30-129
         auto it = texture_by_file_.find(path);
         if (it != texture_by_file_.end()) return it->second;

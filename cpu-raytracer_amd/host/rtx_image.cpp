@@ -521,3 +521,18 @@ extern "C" int rtxh_texture_load(const char * path, int32_t mipmap_mode, float *
 }
 
 extern "C" int rtxh_texture_free(float * texels) { free(texels); return RTX_OK; }
+
+// Sky::Sky (Sky.cpp:8-26): a headerless file of float3 texels of a square angular-map probe (Debevec `.float` files)
+extern "C" int rtxh_sky_load(const char * path, float ** texels_out, int32_t * size_out) {
+    if (!path || !texels_out || !size_out) return RTX_ERR_INVALID_ARG;
+    Bytes file;
+    if (!read_file(path, file)) return RTX_ERR_STATE;                    // the reference aborts
+    const size_t texels = file.size() / 12;                              // ftell / sizeof(Vector3)
+    const int size = (int)sqrtf((float)(int)texels);                     // int(sqrtf(size_squared)), :17
+    if (texels == 0 || texels > 0x7fffffffu || (size_t)size * size != texels) return RTX_ERR_INVALID_ARG;   // assert(size * size == size_squared)
+    float * out = (float *)malloc(texels * 12);
+    if (!out) return RTX_ERR_OOM;
+    memcpy(out, file.data(), texels * 12);
+    *texels_out = out; *size_out = size;
+    return RTX_OK;
+}

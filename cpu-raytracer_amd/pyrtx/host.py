@@ -19,7 +19,7 @@ from .ctypes_structs import RtxCamera, RtxTextureDesc
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "host", "librtx_host.so")
 EXPORTS = ["rtxh_camera_basis", "rtxh_camera_update", "rtxh_quaternion_axis_angle", "rtxh_scene_dynamic_animate", "rtxh_scene_update", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
-           "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_blas_build_reference_sbvh", "rtxh_texture_mips", "rtxh_texture_load", "rtxh_texture_free", "rtxh_image_load", "rtxh_image_free", "rtxh_image_save_png", "rtxh_atrium_generate", "rtxh_mesh_free",
+           "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_blas_build_reference_sbvh", "rtxh_texture_mips", "rtxh_texture_load", "rtxh_texture_free", "rtxh_sky_load", "rtxh_image_load", "rtxh_image_free", "rtxh_image_save_png", "rtxh_atrium_generate", "rtxh_mesh_free",
            "rtxh_obj_load", "rtxh_obj_free"]
 
 PI = np.float32(3.14159265359)          # Util.h:8
@@ -60,6 +60,7 @@ def lib():
         l.rtxh_scene_update.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
         l.rtxh_texture_load.argtypes = [C.c_char_p, i32, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64), C.POINTER(RtxTextureDesc)]
         l.rtxh_texture_free.argtypes = [C.POINTER(C.c_float)]
+        l.rtxh_sky_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(i32)]
         l.rtxh_image_load.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.POINTER(C.c_uint8))]
         l.rtxh_image_free.argtypes = [C.POINTER(C.c_uint8)]
         l.rtxh_image_save_png.argtypes = [C.c_char_p, vp, i32, i32]
@@ -287,6 +288,17 @@ def load_image(path: str) -> np.ndarray:
         raise ValueError(f"rtxh_image_load({path!r}) failed with status {rc}")
     out = np.ctypeslib.as_array(p, (h.value, w.value, 4)).copy()
     lib().rtxh_image_free(p)
+    return out
+
+
+def load_sky(path: str) -> np.ndarray:
+    """Sky::Sky (Sky.cpp:8-26): raw float3 probe file -> (size, size, 3) float32."""
+    p = C.POINTER(C.c_float)(); n = C.c_int32()
+    rc = lib().rtxh_sky_load(path.encode(), C.byref(p), C.byref(n))
+    if rc:
+        raise ValueError(f"rtxh_sky_load({path!r}) failed with status {rc}")
+    out = np.ctypeslib.as_array(p, (n.value, n.value, 3)).copy()
+    lib().rtxh_texture_free(p)
     return out
 
 

@@ -130,3 +130,16 @@ def host_forward(rot):
     inst, _, _ = host.instance_update((0, 0, 0), rot, (-1, -1, -1), (1, 1, 1), 0)
     w = inst["world"][0]                                                            # cells[i + 4 j]: third column = image of z
     return np.array([w[2], w[6], w[10]], np.float32)
+
+
+def test_sky_probe_file_loader(tmp_path):
+    """Sky::Sky (Sky.cpp:8-26): raw float3 texels of a square probe."""
+    sky = host.synthetic_sky(64)
+    p = tmp_path / "probe.float"
+    sky.tofile(str(p))
+    assert np.array_equal(host.load_sky(str(p)), sky)
+    (tmp_path / "bad.float").write_bytes(sky.tobytes()[:12 * 63 * 64])       # 4032 texels: not a square (the reference asserts)
+    with pytest.raises(ValueError):
+        host.load_sky(str(tmp_path / "bad.float"))
+    with pytest.raises(ValueError):
+        host.load_sky(str(tmp_path / "missing.float"))
