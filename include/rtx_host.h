@@ -28,6 +28,7 @@
  *   rtxh_texture_mips        Texture::load's box-filter mip chain          Texture.cpp:76-117
  *   rtxh_texture_load        Texture::load: PNG / TGA file -> linear float3 texels + mips   Texture.cpp:30-129
  *   rtxh_image_load          the stbi_load(..., STBI_rgb_alpha) call inside it  Texture.cpp:40
+ *   rtxh_sky_load            Sky::Sky: raw float3 angular-map probe file         Sky.cpp:8-26
  *   rtxh_atrium_*            seeded procedural stand-in for the absent Sponza mesh
  */
 #ifndef RTX_HOST_H
