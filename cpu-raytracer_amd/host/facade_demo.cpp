@@ -36,6 +36,7 @@ int main(int argc, char ** argv) {
             cfg.SCREEN_WIDTH = h.width; cfg.SCREEN_HEIGHT = h.height; cfg.NUMBER_OF_BOUNCES = h.bounces;
             cfg.MIPMAP_FILTER = std::atoi(argv[4]); cfg.TEXTURE_SAMPLE_MODE = std::atoi(argv[5]);
             rtx::Scene scene(cfg, 110.0f * 3.14159265359f * 0.00555555555f /* DEG_TO_RAD(110), Scene.cpp:75, Util.h:14 */);
+            scene.USE_BVH_CACHE_FILES = std::getenv("RTX_FACADE_BVH_CACHE") != nullptr;      // like the reference: `<obj>.bvh` next to the meshes
             rtx::load_script(argv[2], argv[3], scene);
             scene.camera.resize(cfg.SCREEN_WIDTH, cfg.SCREEN_HEIGHT);
             scene.upload();

@@ -142,18 +142,36 @@ public:
         textures.push_back(std::move(t));
         return texture_by_file_[path] = (int)textures.size() - 1;
     }
-    int load_mesh(const std::string & obj_path) {               // BottomLevelBVH::load, BottomLevelBVH.cpp:18-58 (without the .bvh disk cache)
+    bool USE_BVH_CACHE_FILES = false;                           // BottomLevelBVH::load keeps `<obj>.bvh` next to the mesh (BottomLevelBVH.cpp:26-33,53); off by default here
+    int load_mesh(const std::string & obj_path) {               // BottomLevelBVH::load, BottomLevelBVH.cpp:18-58
         auto it = blas_by_file_.find(obj_path);
         if (it != blas_by_file_.end()) return it->second;
         ensure_default_material();
+        Blas b; b.material_offset = (int)materials.size();      // OBJLoader.cpp:9
+        auto take_materials = [&](rtxh_obj & o) {
+            for (int i = 0; i < o.mesh.material_count; i++) {
+                rtx_material m = o.materials[i];
+                m.texture_id = m.texture_id >= 0 ? load_texture(o.texture_names + (size_t)i * RTXH_TEXNAME_MAX) : -1;
+                materials.push_back(m);
+            }
+        };
+        const std::string cache_path = obj_path + ".bvh";
+        rtxh_bvh_cache cache; std::memset(&cache, 0, sizeof(cache));
+        if (USE_BVH_CACHE_FILES && rtxh_bvh_cache_load(cache_path.c_str(), &cache) == RTX_OK) {          // :28-33: cached tree + load_mtl
+            rtxh_obj o; std::memset(&o, 0, sizeof(o));
+            check(rtxh_mtl_load(obj_path.c_str(), &o), ("OBJLoader::load_mtl " + obj_path).c_str());
+            take_materials(o);
+            rtxh_obj_free(&o);
+            b.nodes.assign(cache.nodes, cache.nodes + cache.node_count);
+            b.hot.resize(cache.index_count); b.cold.resize(cache.index_count);                             // flatten, :196-212
+            for (int k = 0; k < cache.index_count; k++) { b.hot[k] = cache.hot[cache.indices[k]]; b.cold[k] = cache.cold[cache.indices[k]]; }
+            rtxh_bvh_cache_free(&cache);
+            blas.push_back(std::move(b));
+            return blas_by_file_[obj_path] = (int)blas.size() - 1;
+        }
         rtxh_obj o; std::memset(&o, 0, sizeof(o));
         check(rtxh_obj_load(obj_path.c_str(), &o), ("OBJLoader::load_obj " + obj_path).c_str());
-        Blas b; b.material_offset = (int)materials.size();      // OBJLoader.cpp:9
-        for (int i = 0; i < o.mesh.material_count; i++) {
-            rtx_material m = o.materials[i];
-            m.texture_id = m.texture_id >= 0 ? load_texture(o.texture_names + (size_t)i * RTXH_TEXNAME_MAX) : -1;
-            materials.push_back(m);
-        }
+        take_materials(o);
         const int n = o.mesh.triangle_count;
         std::vector<int32_t> order; int node_count = 0, refs = n;
         for (int cap = 2 * n;; cap *= 2) {
@@ -161,16 +179,16 @@ public:
             int rc = MESH_ACCELERATOR == 1
                 ? rtxh_blas_build_reference_sbvh(o.mesh.positions, n, b.nodes.data(), (int)b.nodes.size(), &node_count, order.data(), cap, &refs)
                 : rtxh_blas_build_reference_bvh(o.mesh.positions, n, b.nodes.data(), &node_count, order.data());
-            if (rc == RTX_ERR_LIMIT && MESH_ACCELERATOR == 1) continue;
+            if (rc == RTX_ERR_LIMIT && MESH_ACCELERATOR == 1 && cap < 32 * n) continue;
             if (rc) { rtxh_obj_free(&o); check(rc, "BottomLevelBVH::build"); }
             break;
         }
         b.nodes.resize(node_count);
-        b.hot.resize(refs); b.cold.resize(refs);                // OBJLoader.cpp:156-175 + BottomLevelBVH::flatten :196-212
-        for (int k = 0; k < refs; k++) {
-            const int t = order[k];
+        // unflattened arrays first (what the reference writes to the cache, OBJLoader.cpp:156-175), then BottomLevelBVH::flatten :196-212
+        std::vector<rtx_triangle_hot> hot(n); std::vector<rtx_triangle_cold> cold(n);
+        for (int t = 0; t < n; t++) {
             const float * p = o.mesh.positions + 9 * (size_t)t, * nr = o.mesh.normals + 9 * (size_t)t, * uv = o.mesh.texcoords + 6 * (size_t)t;
-            rtx_triangle_hot & h = b.hot[k]; rtx_triangle_cold & c = b.cold[k];
+            rtx_triangle_hot & h = hot[t]; rtx_triangle_cold & c = cold[t];
             std::memset(&c, 0, sizeof(c));
             for (int d = 0; d < 3; d++) {
                 h.position_0[d] = p[d]; h.position_edge_1[d] = p[3 + d] - p[d]; h.position_edge_2[d] = p[6 + d] - p[d];
@@ -180,6 +198,14 @@ public:
             c.material_id = o.mesh.material_ids[t];
         }
         rtxh_obj_free(&o);
+        if (USE_BVH_CACHE_FILES) {                                                                        // save_to_disk, :53
+            rtxh_bvh_cache w; std::memset(&w, 0, sizeof(w));
+            w.triangle_count = n; w.node_count = node_count; w.index_count = refs;
+            w.hot = hot.data(); w.cold = cold.data(); w.nodes = b.nodes.data(); w.indices = order.data();
+            check(rtxh_bvh_cache_save(cache_path.c_str(), &w), ("BottomLevelBVH::save_to_disk " + cache_path).c_str());
+        }
+        b.hot.resize(refs); b.cold.resize(refs);
+        for (int k = 0; k < refs; k++) { b.hot[k] = hot[order[k]]; b.cold[k] = cold[order[k]]; }
         blas.push_back(std::move(b));
         return blas_by_file_[obj_path] = (int)blas.size() - 1;
     }

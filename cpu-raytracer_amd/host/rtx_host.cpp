@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -681,5 +683,61 @@ extern "C" int rtxh_mesh_free(rtxh_mesh * m) {
     if (!m) return RTX_ERR_INVALID_ARG;
     free(m->positions); free(m->normals); free(m->texcoords); free(m->material_ids);
     memset(m, 0, sizeof(*m));
+    return RTX_OK;
+}
+
+// =================================================================================================
+// `<mesh>.obj.bvh` cache files, BottomLevelBVH::save_to_disk / load_from_disk (BottomLevelBVH.cpp:149-192):
+//   int triangle_count; TriangleHot[n]; TriangleCold[n]; int node_count; BVHNode[node_count]; int index_count; int[index_count]
+// The record layouts are the C ABI's, so the arrays are handed over as they are; BottomLevelBVH::flatten (:196-212) is the caller's gather.
+extern "C" int rtxh_bvh_cache_load(const char * path, rtxh_bvh_cache * out) {
+    if (!path || !out) return RTX_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    FILE * f = fopen(path, "rb");
+    if (!f) return RTX_ERR_STATE;
+    fseek(f, 0, SEEK_END); const long size = ftell(f); fseek(f, 0, SEEK_SET);
+    auto fail = [&](int rc) { fclose(f); rtxh_bvh_cache_free(out); return rc; };
+    int32_t n = 0;
+    if (fread(&n, 4, 1, f) != 1 || n <= 0 || (long long)n * 100 + 12 > size) return fail(RTX_ERR_INVALID_ARG);
+    out->triangle_count = n;
+    out->hot = (rtx_triangle_hot *)malloc(sizeof(rtx_triangle_hot) * (size_t)n);
+    out->cold = (rtx_triangle_cold *)malloc(sizeof(rtx_triangle_cold) * (size_t)n);
+    if (!out->hot || !out->cold) return fail(RTX_ERR_OOM);
+    if (fread(out->hot, sizeof(rtx_triangle_hot), n, f) != (size_t)n || fread(out->cold, sizeof(rtx_triangle_cold), n, f) != (size_t)n) return fail(RTX_ERR_INVALID_ARG);
+    int32_t nodes = 0;
+    if (fread(&nodes, 4, 1, f) != 1 || nodes <= 0 || (long long)nodes * 32 > size) return fail(RTX_ERR_INVALID_ARG);
+    out->node_count = nodes;
+    out->nodes = (rtx_bvh_node *)malloc(sizeof(rtx_bvh_node) * (size_t)nodes);
+    if (!out->nodes) return fail(RTX_ERR_OOM);
+    if (fread(out->nodes, sizeof(rtx_bvh_node), nodes, f) != (size_t)nodes) return fail(RTX_ERR_INVALID_ARG);
+    int32_t idx = 0;
+    if (fread(&idx, 4, 1, f) != 1 || idx <= 0 || (long long)idx * 4 > size) return fail(RTX_ERR_INVALID_ARG);
+    out->index_count = idx;
+    out->indices = (int32_t *)malloc(4 * (size_t)idx);
+    if (!out->indices) return fail(RTX_ERR_OOM);
+    if (fread(out->indices, 4, idx, f) != (size_t)idx) return fail(RTX_ERR_INVALID_ARG);
+    for (int i = 0; i < idx; i++) if (out->indices[i] < 0 || out->indices[i] >= n) return fail(RTX_ERR_INVALID_ARG);
+    if (ftell(f) != size) return fail(RTX_ERR_INVALID_ARG);          // trailing bytes: not a cache file of this layout
+    fclose(f);
+    return RTX_OK;
+}
+
+extern "C" int rtxh_bvh_cache_save(const char * path, const rtxh_bvh_cache * c) {
+    if (!path || !c || c->triangle_count <= 0 || c->node_count <= 0 || c->index_count <= 0 || !c->hot || !c->cold || !c->nodes || !c->indices) return RTX_ERR_INVALID_ARG;
+    FILE * f = fopen(path, "wb");
+    if (!f) return RTX_ERR_STATE;
+    bool ok = fwrite(&c->triangle_count, 4, 1, f) == 1
+           && fwrite(c->hot, sizeof(rtx_triangle_hot), c->triangle_count, f) == (size_t)c->triangle_count
+           && fwrite(c->cold, sizeof(rtx_triangle_cold), c->triangle_count, f) == (size_t)c->triangle_count
+           && fwrite(&c->node_count, 4, 1, f) == 1 && fwrite(c->nodes, sizeof(rtx_bvh_node), c->node_count, f) == (size_t)c->node_count
+           && fwrite(&c->index_count, 4, 1, f) == 1 && fwrite(c->indices, 4, c->index_count, f) == (size_t)c->index_count;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? RTX_OK : RTX_ERR_STATE;
+}
+
+extern "C" int rtxh_bvh_cache_free(rtxh_bvh_cache * c) {
+    if (!c) return RTX_ERR_INVALID_ARG;
+    free(c->hot); free(c->cold); free(c->nodes); free(c->indices);
+    memset(c, 0, sizeof(*c));
     return RTX_OK;
 }

@@ -201,6 +201,30 @@ void load_mtl(const std::string & path, std::vector<Mtl> & mats, std::map<std::s
 
 }  // namespace
 
+// materials, OBJLoader.cpp:8-41
+static int fill_materials(rtxh_obj * out, const std::vector<Mtl> & mats, const std::string & dir) {
+    rtxh_mesh & m = out->mesh;
+    const int nm = mats.empty() ? 1 : (int)mats.size();
+    m.material_count = nm;
+    out->materials = (rtx_material *)calloc((size_t)nm, sizeof(rtx_material));
+    out->texture_names = (char *)calloc((size_t)nm, RTXH_TEXNAME_MAX);
+    if (!out->materials || !out->texture_names) return RTX_ERR_OOM;
+    if (mats.empty()) {
+        rtx_material & d = out->materials[0];
+        d.diffuse[0] = 1.0f; d.diffuse[1] = 0.0f; d.diffuse[2] = 1.0f; d.texture_id = -1; d.index_of_refraction = 1.0f;   // magenta, :31-38
+    } else for (int i = 0; i < nm; i++) {
+        rtx_material & d = out->materials[i];
+        memcpy(d.diffuse, mats[i].kd, 12); memcpy(d.reflection, mats[i].ks, 12); memcpy(d.transmittance, mats[i].kt, 12);
+        d.index_of_refraction = mats[i].ni;
+        d.texture_id = -1;
+        if (!mats[i].map_kd.empty()) {
+            d.texture_id = i;                                                       // index into texture_names; the caller de-duplicates
+            snprintf(out->texture_names + (size_t)i * RTXH_TEXNAME_MAX, RTXH_TEXNAME_MAX, "%s%s", dir.c_str(), mats[i].map_kd.c_str());
+        }
+    }
+    return RTX_OK;
+}
+
 extern "C" int rtxh_obj_load(const char * path, rtxh_obj * out) {
     if (!path || !out) return RTX_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
@@ -272,26 +296,24 @@ extern "C" int rtxh_obj_load(const char * path, rtxh_obj * out) {
         }
         m.material_ids[i] = tri_mat[i] < 0 ? 0 : tri_mat[i];                      // OBJLoader.cpp:172-173
     }
-    // materials, OBJLoader.cpp:8-41
-    const int nm = mats.empty() ? 1 : (int)mats.size();
-    m.material_count = nm;
-    out->materials = (rtx_material *)calloc((size_t)nm, sizeof(rtx_material));
-    out->texture_names = (char *)calloc((size_t)nm, RTXH_TEXNAME_MAX);
-    if (!out->materials || !out->texture_names) return RTX_ERR_OOM;
-    if (mats.empty()) {
-        rtx_material & d = out->materials[0];
-        d.diffuse[0] = 1.0f; d.diffuse[1] = 0.0f; d.diffuse[2] = 1.0f; d.texture_id = -1; d.index_of_refraction = 1.0f;   // magenta, :31-38
-    } else for (int i = 0; i < nm; i++) {
-        rtx_material & d = out->materials[i];
-        memcpy(d.diffuse, mats[i].kd, 12); memcpy(d.reflection, mats[i].ks, 12); memcpy(d.transmittance, mats[i].kt, 12);
-        d.index_of_refraction = mats[i].ni;
-        d.texture_id = -1;
-        if (!mats[i].map_kd.empty()) {
-            d.texture_id = i;                                                       // index into texture_names; the caller de-duplicates
-            snprintf(out->texture_names + (size_t)i * RTXH_TEXNAME_MAX, RTXH_TEXNAME_MAX, "%s%s", dir.c_str(), mats[i].map_kd.c_str());
-        }
-    }
-    return RTX_OK;
+    return fill_materials(out, mats, dir);
+}
+
+// OBJLoader::load_mtl (OBJLoader.cpp:43-68): the material half alone, for a mesh whose geometry comes from a `.bvh` cache file
+// (BottomLevelBVH.cpp:28-33).  The .mtl is the one NAMED LIKE THE OBJ (<name>.obj -> <name>.mtl), not the OBJ's mtllib line.
+extern "C" int rtxh_mtl_load(const char * obj_path, rtxh_obj * out) {
+    if (!obj_path || !out) return RTX_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    std::string path(obj_path);
+    if (path.size() < 4) return RTX_ERR_INVALID_ARG;
+    std::string dir(path); { size_t s = dir.find_last_of('/'); dir = s == std::string::npos ? "" : dir.substr(0, s + 1); }
+    const std::string mtl = path.substr(0, path.size() - 4) + ".mtl";
+    FILE * probe = fopen(mtl.c_str(), "rb");
+    if (!probe) return RTX_ERR_STATE;                              // the reference prints a warning and registers no material at all
+    fclose(probe);
+    std::vector<Mtl> mats; std::map<std::string, int> by_name;
+    load_mtl(mtl, mats, by_name);
+    return fill_materials(out, mats, dir);
 }
 
 extern "C" int rtxh_obj_free(rtxh_obj * o) {

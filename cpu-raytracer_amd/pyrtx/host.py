@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "host", "librtx_host.so")
 EXPORTS = ["rtxh_camera_basis", "rtxh_camera_update", "rtxh_quaternion_axis_angle", "rtxh_scene_dynamic_animate", "rtxh_scene_update", "rtxh_instance_update", "rtxh_plane_update", "rtxh_tlas_create", "rtxh_tlas_destroy",
            "rtxh_tlas_build", "rtxh_blas_build", "rtxh_blas_build_reference_bvh", "rtxh_blas_build_reference_sbvh", "rtxh_texture_mips", "rtxh_texture_load", "rtxh_texture_free", "rtxh_sky_load", "rtxh_image_load", "rtxh_image_free", "rtxh_image_save_png", "rtxh_atrium_generate", "rtxh_mesh_free",
-           "rtxh_obj_load", "rtxh_obj_free"]
+           "rtxh_obj_load", "rtxh_obj_free", "rtxh_mtl_load", "rtxh_bvh_cache_load", "rtxh_bvh_cache_save", "rtxh_bvh_cache_free"]
 
 PI = np.float32(3.14159265359)          # Util.h:8
 
@@ -32,6 +32,11 @@ class RtxhMesh(C.Structure):
 
 class RtxhObj(C.Structure):
     _fields_ = [("mesh", RtxhMesh), ("materials", C.c_void_p), ("texture_names", C.c_void_p)]
+
+
+class RtxhBvhCache(C.Structure):
+    _fields_ = [("triangle_count", C.c_int32), ("node_count", C.c_int32), ("index_count", C.c_int32), ("pad", C.c_int32),
+                ("hot", C.c_void_p), ("cold", C.c_void_p), ("nodes", C.c_void_p), ("indices", C.c_void_p)]
 
 
 TEXNAME_MAX = 512
@@ -67,6 +72,10 @@ def lib():
         l.rtxh_blas_build_reference_sbvh.argtypes = [vp, i32, vp, i32, C.POINTER(i32), vp, i32, C.POINTER(i32)]
         l.rtxh_obj_load.argtypes = [C.c_char_p, C.POINTER(RtxhObj)]
         l.rtxh_obj_free.argtypes = [C.POINTER(RtxhObj)]
+        l.rtxh_mtl_load.argtypes = [C.c_char_p, C.POINTER(RtxhObj)]
+        l.rtxh_bvh_cache_load.argtypes = [C.c_char_p, C.POINTER(RtxhBvhCache)]
+        l.rtxh_bvh_cache_save.argtypes = [C.c_char_p, C.POINTER(RtxhBvhCache)]
+        l.rtxh_bvh_cache_free.argtypes = [C.POINTER(RtxhBvhCache)]
         l.rtxh_texture_mips.argtypes = [vp, i32, i32, C.POINTER(RtxTextureDesc), C.POINTER(C.c_int64)]
         l.rtxh_atrium_generate.argtypes = [C.c_uint32, i32, C.POINTER(RtxhMesh)]
         l.rtxh_mesh_free.argtypes = [C.POINTER(RtxhMesh)]
@@ -254,6 +263,23 @@ def load_bvh_cache(path: str, material_offset: int = 0) -> sio.Blas:
     assert off + 4 * ic == len(buf), "trailing bytes in .bvh cache"
     if nc > 1:
         nodes[1] = np.zeros(1, sio.BVH_NODE)[0]           # never written by the reference (uninitialised heap in the file)
+    return sio.Blas(nodes, hot[idx].copy(), cold[idx].copy(), material_offset, n)
+
+
+def load_bvh_cache_native(path: str, material_offset: int = 0, keep_node1: bool = False) -> sio.Blas:
+    """The same file through librtx_host's rtxh_bvh_cache_load (the C / C++ route), flattened like BottomLevelBVH::flatten."""
+    c = RtxhBvhCache()
+    rc = lib().rtxh_bvh_cache_load(path.encode(), C.byref(c))
+    if rc:
+        raise ValueError(f"rtxh_bvh_cache_load({path!r}) failed with status {rc}")
+    def arr(ptr, dtype, n):
+        return np.frombuffer((C.c_char * (n * dtype.itemsize)).from_address(ptr), dtype, n).copy()
+    hot = arr(c.hot, sio.TRI_HOT, c.triangle_count); cold = arr(c.cold, sio.TRI_COLD, c.triangle_count)
+    nodes = arr(c.nodes, sio.BVH_NODE, c.node_count); idx = arr(c.indices, np.dtype(np.int32), c.index_count)
+    n = c.triangle_count
+    lib().rtxh_bvh_cache_free(C.byref(c))
+    if len(nodes) > 1 and not keep_node1:
+        nodes[1] = np.zeros(1, sio.BVH_NODE)[0]
     return sio.Blas(nodes, hot[idx].copy(), cold[idx].copy(), material_offset, n)
 
 

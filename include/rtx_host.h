@@ -25,6 +25,8 @@
  *   rtxh_blas_build_reference_sbvh  the reference's DEFAULT BLAS builder (MESH_ACCELERATOR_SBVH, Config.h:35): spatial
  *                            splits + reference unsplitting, node for node     BVHBuilders.h:48-329, BVHPartitions.h:117-377
  *   rtxh_obj_load            OBJLoader::load_obj / load_mtl                 OBJLoader.cpp:8-187
+ *   rtxh_mtl_load            OBJLoader::load_mtl alone                       OBJLoader.cpp:43-68
+ *   rtxh_bvh_cache_*         BottomLevelBVH::save_to_disk / load_from_disk   BottomLevelBVH.cpp:149-192
  *   rtxh_texture_mips        Texture::load's box-filter mip chain          Texture.cpp:76-117
  *   rtxh_texture_load        Texture::load: PNG / TGA file -> linear float3 texels + mips   Texture.cpp:30-129
  *   rtxh_image_load          the stbi_load(..., STBI_rgb_alpha) call inside it  Texture.cpp:40
@@ -142,6 +144,22 @@ typedef struct rtxh_obj {
 } rtxh_obj;
 int rtxh_obj_load(const char * path, rtxh_obj * out);                        /* allocates; free with rtxh_obj_free */
 int rtxh_obj_free(rtxh_obj * o);
+/* OBJLoader::load_mtl (OBJLoader.cpp:43-68): materials only, from the .mtl named like the OBJ — what BottomLevelBVH::load registers when the
+ * geometry comes from a `.bvh` cache file (BottomLevelBVH.cpp:28-33).  out->mesh stays empty except material_count.                          */
+int rtxh_mtl_load(const char * obj_path, rtxh_obj * out);
+
+/* `<mesh>.obj.bvh` cache files exactly as BottomLevelBVH::save_to_disk / load_from_disk read and write them (BottomLevelBVH.cpp:149-192).
+ * The arrays are NOT flattened: triangle i of a leaf is hot[indices[i]] (BottomLevelBVH::flatten, :196-212, is the caller's gather).          */
+typedef struct rtxh_bvh_cache {
+    int32_t triangle_count, node_count, index_count, pad;
+    rtx_triangle_hot *  hot;       /* triangle_count */
+    rtx_triangle_cold * cold;      /* triangle_count */
+    rtx_bvh_node *      nodes;     /* node_count */
+    int32_t *           indices;   /* index_count */
+} rtxh_bvh_cache;
+int rtxh_bvh_cache_load(const char * path, rtxh_bvh_cache * out);            /* allocates; free with rtxh_bvh_cache_free */
+int rtxh_bvh_cache_save(const char * path, const rtxh_bvh_cache * cache);
+int rtxh_bvh_cache_free(rtxh_bvh_cache * cache);
 
 #ifdef __cplusplus
 }

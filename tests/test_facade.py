@@ -52,3 +52,29 @@ def test_facade_builds_the_scene_from_asset_files(name, script, extra, mip_filte
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert [res["primary"], res["shadow"], res["reflection"], res["refraction"]] == g["stats"].tolist()
     assert res["fnv1a"] == fnv1a(g["packed"].reshape(-1))
+
+
+def test_facade_bvh_cache_files_like_the_reference(tmp_path):
+    """BottomLevelBVH::load keeps `<mesh>.obj.bvh` next to the mesh (BottomLevelBVH.cpp:26-33,53).  With the facade's USE_BVH_CACHE_FILES
+    the first run writes the files, the second loads them (OBJLoader::load_mtl for the materials); both runs give the reference's frame,
+    and the Torus cache equals the file the REAL reference wrote except for the node the reference never initialises (index 1)."""
+    import shutil
+    data = tmp_path / "Data"
+    shutil.copytree(os.path.join(util.GOLDEN, "meshes"), data)
+    _, g = util.load_golden("materials_aniso")
+    s = tmp_path / "scene.txt"
+    s.write_text(open(os.path.join(util.GOLDEN, "scripts", "materials.txt")).read() + "\nsize 320 180\nmatset mesh:0:0 texture ./Data/LEGOSHLD.tga\n")
+    exe = os.path.join(util.REPO, "cpu-raytracer_amd", "host", "facade_demo")
+    env = dict(os.environ, RTX_FACADE_BVH_CACHE="1")
+    for run in range(2):
+        out = subprocess.run([exe, "--script", str(s), str(data), "1", "2"], capture_output=True, text=True, timeout=120, env=env)
+        assert out.returncode == 0, out.stderr
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+        assert res["fnv1a"] == fnv1a(g["packed"].reshape(-1)), run
+        assert (data / "Torus.obj.bvh").exists() and (data / "Monkey.obj.bvh").exists()
+    mine = bytearray((data / "Torus.obj.bvh").read_bytes())
+    ref = bytearray(open(os.path.join(util.GOLDEN, "bvh_cache", "Torus.obj.bvh"), "rb").read())
+    n = int(np.frombuffer(bytes(ref[:4]), np.int32)[0])
+    node1 = 4 + n * 100 + 4 + 32
+    mine[node1:node1 + 32] = ref[node1:node1 + 32]
+    assert mine == ref

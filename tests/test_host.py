@@ -143,3 +143,39 @@ def test_sky_probe_file_loader(tmp_path):
         host.load_sky(str(tmp_path / "bad.float"))
     with pytest.raises(ValueError):
         host.load_sky(str(tmp_path / "missing.float"))
+
+
+@pytest.mark.parametrize("mesh", ["Cube", "Torus"])
+def test_native_bvh_cache_io(mesh, tmp_path):
+    """rtxh_bvh_cache_load / _save (C): files written by the REAL reference load into the same BLAS as through the Python reader,
+    and a load -> save round trip reproduces the reference's file byte for byte."""
+    import ctypes as C
+    import os
+    src = os.path.join(util.GOLDEN, "bvh_cache", mesh + ".obj.bvh")
+    a, b = host.load_bvh_cache(src), host.load_bvh_cache_native(src)
+    assert a.nodes.tobytes() == b.nodes.tobytes() and a.tri_hot.tobytes() == b.tri_hot.tobytes() and a.tri_cold.tobytes() == b.tri_cold.tobytes()
+    c = host.RtxhBvhCache()
+    assert host.lib().rtxh_bvh_cache_load(src.encode(), C.byref(c)) == 0
+    out = str(tmp_path / "copy.bvh")
+    assert host.lib().rtxh_bvh_cache_save(out.encode(), C.byref(c)) == 0
+    host.lib().rtxh_bvh_cache_free(C.byref(c))
+    assert open(out, "rb").read() == open(src, "rb").read()
+    raw = open(src, "rb").read()
+    for bad in (raw[:len(raw) // 2], raw + b"\\0\\0\\0\\0", b"\\xff\\xff\\xff\\x7f" + raw[4:], b""):       # truncated, trailing bytes, absurd count, empty
+        p = tmp_path / "bad.bvh"; p.write_bytes(bad)
+        with pytest.raises(ValueError):
+            host.load_bvh_cache_native(str(p))
+
+
+def test_mtl_only_loader_matches_the_obj_loader(tmp_path):
+    import ctypes as C
+    import os
+    obj = os.path.join(util.GOLDEN, "meshes", "Cube.obj")
+    full = host.load_obj(obj)
+    o = host.RtxhObj()
+    assert host.lib().rtxh_mtl_load(obj.encode(), C.byref(o)) == 0
+    n = o.mesh.material_count
+    mats = np.frombuffer((C.c_char * (n * sio.MATERIAL.itemsize)).from_address(o.materials), sio.MATERIAL, n).copy()
+    host.lib().rtxh_obj_free(C.byref(o))
+    assert mats.tobytes() == full[4].tobytes()
+    assert host.lib().rtxh_mtl_load(str(tmp_path / "none.obj").encode(), C.byref(o)) == 5
