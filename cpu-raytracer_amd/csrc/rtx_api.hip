@@ -23,6 +23,7 @@
 #include "rtx_libm.h"
 #include "rtx_texture.h"
 #include "rtx_trace.h"
+#include "rtx_packet.h"
 #include "rtx_shade.h"
 #include "rtx_present.h"
 
@@ -51,17 +52,18 @@ struct rtx_ctx {
     std::vector<void *> tex_allocs;
     int material_count = 0, sky_size = 0;
     // host copies for validate_references(): every id a kernel will follow is checked on the host before anything is launched
-    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material; std::vector<int> frame_primitive_materials; bool refs_dirty = true;
+    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true;
 
-    DevBuf f_tlas, f_tlas_idx, f_inst, f_sph, f_pln, f_pl, f_sl, f_dl;
+    DevBuf f_tlas, f_tlas_pk, f_tlas_idx, f_inst, f_sph, f_pln, f_pl, f_sl, f_dl;
     DevScene scene;
     bool frame_set = false;
 
     DevQueues q;
     DevBuf qb[20];
     size_t slots_alloc = 0, shadow_alloc = 0;
-    DevBuf d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma;
+    DevBuf d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma, d_pk_heads;
     int trace_blocks_closest = 0, trace_blocks_any = 0, trace_blocks_count = 0;
+    int pk_blocks_closest = 0, pk_blocks_any = 0;    // persistent grids of the packet kernels (even: waves % 8 == 0, see k_begin_batch)
     bool merge_any = true;               // one-stream mode: ONE shadow-ray launch for all levels after the last shade (RTX_SERIAL_MERGE_ANY=0: one per level)
 
     rtx_stats stats_acc; rtx_work_counters work_acc; uint32_t err_flags_acc = 0;
@@ -101,6 +103,17 @@ static void convert_nodes(const rtx_bvh_node * nodes, int n, std::vector<float4>
         memcpy(&l, &nodes[i].left_or_first, 4); memcpy(&cnt, &nodes[i].count, 4);
         out[2 * i]     = make_float4(nodes[i].aabb_min[0], nodes[i].aabb_min[1], nodes[i].aabb_min[2], l);
         out[2 * i + 1] = make_float4(nodes[i].aabb_max[0], nodes[i].aabb_max[1], nodes[i].aabb_max[2], cnt);
+    }
+}
+
+// the packet kernels' node record: every SGPR pair of a fetched node is one operand of a packed-fp32 instruction (rtx_packet.h)
+static void convert_nodes_pk(const rtx_bvh_node * nodes, int n, std::vector<float4> & out) {
+    out.resize((size_t)2 * (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        float l, cnt;
+        memcpy(&l, &nodes[i].left_or_first, 4); memcpy(&cnt, &nodes[i].count, 4);
+        out[2 * i]     = make_float4(nodes[i].aabb_min[0], nodes[i].aabb_min[1], nodes[i].aabb_max[0], nodes[i].aabb_max[1]);
+        out[2 * i + 1] = make_float4(nodes[i].aabb_min[2], nodes[i].aabb_max[2], l, cnt);
     }
 }
 
@@ -155,6 +168,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     if (!rc) rc = ensure(c, c->d_fb_rgb, px * 12);
     if (!rc) rc = ensure(c, c->d_fb_packed, px * 4);
     if (!rc) rc = ensure(c, c->d_counters, sizeof(DevCounters));
+    if (!rc) rc = ensure(c, c->d_pk_heads, (size_t)2 * (RTX_MAX_LEVELS + 1) * RTX_PK_CLASSES * 32 * sizeof(uint32_t));
     float zero_sky[6] = { 0, 0, 0, 0, 0, 0 };
     if (!rc) rc = upload(c, c->d_sky, zero_sky, sizeof(zero_sky));
     c->sky_size = 1;
@@ -170,8 +184,16 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->trace_blocks_any = c->n_cu * (bpc > 0 ? bpc : 2);
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace<false, true>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_count = c->n_cu * (bpc > 0 ? bpc : 2);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_packet<false, false>, RTX_PK_BLOCK, 0);
+    c->pk_blocks_closest = (c->n_cu * (bpc > 0 ? bpc : 4) + 1) & ~1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_packet<true, false>, RTX_PK_BLOCK, 0);
+    c->pk_blocks_any = (c->n_cu * (bpc > 0 ? bpc : 4) + 1) & ~1;
+    if (const char * e = getenv("RTX_PK_GRID_SCALE")) { const double f = atof(e); if (f > 0.0) { c->pk_blocks_closest = ((int)(c->pk_blocks_closest * f) + 1) & ~1; c->pk_blocks_any = ((int)(c->pk_blocks_any * f) + 1) & ~1; } }
     int max_blocks = c->trace_blocks_closest > c->trace_blocks_any ? c->trace_blocks_closest : c->trace_blocks_any;
     if (c->trace_blocks_count > max_blocks) max_blocks = c->trace_blocks_count;
+    if (c->pk_blocks_any > max_blocks) max_blocks = c->pk_blocks_any;       // the packet kernels' per-lane phase spills there too
+    if (c->pk_blocks_closest > max_blocks) max_blocks = c->pk_blocks_closest;
+    c->q.pk_defer_t0 = 8; if (const char * e = getenv("RTX_PK_DEFER")) c->q.pk_defer_t0 = atoi(e);
     c->q.spill_threads = max_blocks * RTX_TRACE_BLOCK;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast
     if (rc) { rtx_destroy(c); return rc; }
@@ -185,8 +207,8 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto & v : c->blas_allocs) for (void * p : v) hipFree(p);
     for (void * p : c->tex_allocs) hipFree(p);
-    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->f_tlas, &c->f_tlas_idx, &c->f_inst, &c->f_sph,
-                        &c->f_pln, &c->f_pl, &c->f_sl, &c->f_dl, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma };
+    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->f_tlas, &c->f_tlas_pk, &c->f_tlas_idx, &c->f_inst, &c->f_sph,
+                        &c->f_pln, &c->f_pl, &c->f_sl, &c->f_dl, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads };
     for (DevBuf * b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf & b : c->qb) if (b.p) hipFree(b.p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
@@ -203,18 +225,21 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
 // Walks the nodes a traversal can reach from the root (abandoned child pairs and index 1 hold garbage in reference-built arrays and are
 // not looked at): every leaf range inside the primitive array, every child pair inside the node array, and no node reachable twice —
 // a cycle would keep a GPU traversal going for ever.
-static bool validate_tree(const rtx_bvh_node * nodes, int node_count, int64_t primitive_count) {
+static bool validate_tree(const rtx_bvh_node * nodes, int node_count, int64_t primitive_count, int * max_inner_depth = nullptr, int * max_leaf_count = nullptr) {
     if (node_count < 1) return false;
     std::vector<unsigned char> seen((size_t)node_count, 0);
-    std::vector<int> stack(1, 0);
+    std::vector<std::pair<int, int>> stack(1, std::make_pair(0, 0));       // node, depth
+    int deepest = -1, biggest = 0;
     while (!stack.empty()) {
-        const int i = stack.back(); stack.pop_back();
+        const int i = stack.back().first, d = stack.back().second; stack.pop_back();
         if (seen[i]) return false;
         seen[i] = 1;
         const int cnt = nodes[i].count & 0x3fffffff, f = nodes[i].left_or_first;
-        if (cnt > 0) { if (f < 0 || (int64_t)f + cnt > primitive_count) return false; }
-        else { if (f < 0 || f + 1 >= node_count) return false; stack.push_back(f); stack.push_back(f + 1); }
+        if (cnt > 0) { if (f < 0 || (int64_t)f + cnt > primitive_count) return false; if (cnt > biggest) biggest = cnt; }
+        else { if (f < 0 || f + 1 >= node_count) return false; if (d > deepest) deepest = d; stack.push_back(std::make_pair(f, d + 1)); stack.push_back(std::make_pair(f + 1, d + 1)); }
     }
+    if (max_inner_depth) *max_inner_depth = deepest;
+    if (max_leaf_count) *max_leaf_count = biggest;
     return true;
 }
 
@@ -226,7 +251,8 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
         return RTX_ERR_INVALID_ARG;
     hipSetDevice(c->cfg.device);
     // every leaf must address triangles inside the arrays, every inner node children inside the node array
-    if (!validate_tree(nodes, node_count, triangle_count)) return RTX_ERR_INVALID_ARG;
+    int inner_depth = -1, leaf_max = 0;
+    if (!validate_tree(nodes, node_count, triangle_count, &inner_depth, &leaf_max)) return RTX_ERR_INVALID_ARG;
     if ((size_t)blas_id >= c->h_blas.size()) { c->h_blas.resize(blas_id + 1); c->blas_allocs.resize(blas_id + 1); for (auto & b : c->h_blas) if (!b.nodes) memset(&b, 0, sizeof(b)); }
     for (void * p : c->blas_allocs[blas_id]) hipFree(p);
     c->blas_allocs[blas_id].clear();
@@ -238,8 +264,11 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
         th[RTX_TRI_STRIDE * (size_t)i + 1] = make_float4(tri_hot[i].position_edge_1[0], tri_hot[i].position_edge_1[1], tri_hot[i].position_edge_1[2], 0.0f);
         th[RTX_TRI_STRIDE * (size_t)i + 2] = make_float4(tri_hot[i].position_edge_2[0], tri_hot[i].position_edge_2[1], tri_hot[i].position_edge_2[2], 0.0f);
     }
-    void * dn = nullptr, * dt = nullptr, * dc = nullptr;
+    std::vector<float4> ndp; convert_nodes_pk(nodes, node_count, ndp);
+    void * dn = nullptr, * dt = nullptr, * dc = nullptr, * dnp = nullptr;
     HIP_OK(c, hipMalloc(&dn, nd.size() * 16)); c->blas_allocs[blas_id].push_back(dn);
+    HIP_OK(c, hipMalloc(&dnp, ndp.size() * 16)); c->blas_allocs[blas_id].push_back(dnp);
+    HIP_OK(c, hipMemcpy(dnp, ndp.data(), ndp.size() * 16, hipMemcpyHostToDevice));
     HIP_OK(c, hipMalloc(&dt, th.size() * 16)); c->blas_allocs[blas_id].push_back(dt);
     HIP_OK(c, hipMalloc(&dc, (size_t)(triangle_count > 0 ? triangle_count : 1) * sizeof(rtx_triangle_cold))); c->blas_allocs[blas_id].push_back(dc);
     HIP_OK(c, hipMemcpy(dn, nd.data(), nd.size() * 16, hipMemcpyHostToDevice));
@@ -249,8 +278,12 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
     int max_local = -1;
     for (int i = 0; i < triangle_count; i++) { if (tri_cold[i].material_id < 0) return RTX_ERR_INVALID_ARG; if (tri_cold[i].material_id > max_local) max_local = tri_cold[i].material_id; }
     c->blas_max_local_material[blas_id] = max_local; c->refs_dirty = true;
+    if (c->blas_inner_depth.size() <= (size_t)blas_id) { c->blas_inner_depth.resize(blas_id + 1, -1); c->blas_packet_ok.resize(blas_id + 1, 1); }
+    c->blas_inner_depth[blas_id] = inner_depth;
+    // the packet kernels pack stack entries and address nodes / triangles with 32-bit byte offsets (rtx_packet.h)
+    c->blas_packet_ok[blas_id] = (leaf_max < 65536 && node_count < (1 << 26) && triangle_count < (1 << 25)) ? 1 : 0;
     DevBlas & B = c->h_blas[blas_id];
-    B.nodes = (const float4 *)dn; B.tri_hot = (const float4 *)dt; B.tri_cold = (const rtx_triangle_cold *)dc;
+    B.nodes = (const float4 *)dn; B.pk_nodes = (const float4 *)dnp; B.tri_hot = (const float4 *)dt; B.tri_cold = (const rtx_triangle_cold *)dc;
     B.node_count = node_count; B.tri_count = triangle_count; B.material_offset = material_offset; B.pad = 0;
     return upload(c, c->d_blas, c->h_blas.data(), c->h_blas.size() * sizeof(DevBlas));
 }
@@ -303,7 +336,8 @@ extern "C" int rtx_set_frame(rtx_ctx * c, const rtx_frame * f) {
     if (f->instance_count >= (1 << 28) || f->sphere_count >= (1 << 28) || f->plane_count >= (1 << 28)) return RTX_ERR_LIMIT;
     hipSetDevice(c->cfg.device);
     // validate the TLAS against the instance table and the instances against the uploaded BLAS set
-    if (f->tlas_node_count > 0 && !validate_tree(f->tlas_nodes, f->tlas_node_count, f->tlas_index_count)) return RTX_ERR_INVALID_ARG;
+    int tlas_depth = -1;
+    if (f->tlas_node_count > 0 && !validate_tree(f->tlas_nodes, f->tlas_node_count, f->tlas_index_count, &tlas_depth)) return RTX_ERR_INVALID_ARG;
     for (int i = 0; i < f->tlas_index_count; i++) if (f->tlas_indices[i] < 0 || f->tlas_indices[i] >= f->instance_count) return RTX_ERR_INVALID_ARG;
     for (int i = 0; i < f->instance_count; i++) {
         const int b = f->instances[i].blas_id;
@@ -313,6 +347,7 @@ extern "C" int rtx_set_frame(rtx_ctx * c, const rtx_frame * f) {
 
     std::vector<float4> nd; convert_nodes(f->tlas_nodes, f->tlas_node_count, nd);
     int rc = upload(c, c->f_tlas, nd.data(), nd.size() * 16);
+    if (!rc) { std::vector<float4> ndp; convert_nodes_pk(f->tlas_nodes, f->tlas_node_count, ndp); rc = upload(c, c->f_tlas_pk, ndp.data(), ndp.size() * 16); }
     if (!rc) rc = upload(c, c->f_tlas_idx, f->tlas_indices, (size_t)f->tlas_index_count * 4);
     if (!rc) rc = upload(c, c->f_inst, f->instances, (size_t)f->instance_count * sizeof(rtx_instance));
     if (!rc) rc = upload(c, c->f_sph, f->spheres, (size_t)f->sphere_count * sizeof(rtx_sphere));
@@ -337,7 +372,7 @@ extern "C" int rtx_set_frame(rtx_ctx * c, const rtx_frame * f) {
     s.textures = (const DevTexture *)c->d_textures.p; s.texture_count = (int)c->h_tex.size();
     s.sky = (const float *)c->d_sky.p; s.sky_size = c->sky_size;
     s.ewa_table = (const float *)c->d_ewa.p;
-    s.tlas_nodes = (const float4 *)c->f_tlas.p; s.tlas_node_count = f->tlas_node_count;
+    s.tlas_nodes = (const float4 *)c->f_tlas.p; s.tlas_node_count = f->tlas_node_count; s.pk_tlas_nodes = (const float4 *)c->f_tlas_pk.p;
     s.tlas_indices = (const int32_t *)c->f_tlas_idx.p; s.tlas_index_count = f->tlas_index_count;
     s.instances = (const rtx_instance *)c->f_inst.p; s.instance_count = f->instance_count;
     s.spheres = (const rtx_sphere *)c->f_sph.p; s.sphere_count = f->sphere_count;
@@ -349,6 +384,7 @@ extern "C" int rtx_set_frame(rtx_ctx * c, const rtx_frame * f) {
     c->frame_primitive_materials.clear();
     for (int i = 0; i < f->sphere_count; i++) c->frame_primitive_materials.push_back(f->spheres[i].material_id);
     for (int i = 0; i < f->plane_count; i++) c->frame_primitive_materials.push_back(f->planes[i].material_id);
+    c->tlas_inner_depth = tlas_depth;
     c->frame_set = true; c->refs_dirty = true;
     return RTX_OK;
 }
@@ -364,6 +400,16 @@ static int validate_references(rtx_ctx * c) {
         const int hi = b < c->blas_max_local_material.size() ? c->blas_max_local_material[b] : -1;
         if (c->h_blas[b].material_offset < 0 || (hi >= 0 && (long long)c->h_blas[b].material_offset + hi >= nm)) { c->err = "BLAS material_offset + triangle material id outside the uploaded material table"; return RTX_ERR_STATE; }
     }
+    // BVH_TRAVERSAL_STACK_SIZE (Config.h:25).  The reference's per-BVH stack holds one pending sibling per ancestor entered through its near
+    // child plus the two children pushed while a node is expanded (BottomLevelBVH.cpp:381-387, TopLevelBVH.cpp:76-82) and is not checked:
+    // a tree with an inner node at depth d overflows a stack of fewer than d + 2 entries for some ray.  Such a tree is refused here,
+    // for every ray alike; the kernels' own stacks (64 entries) can then never overflow.
+    for (size_t b = 0; b < c->h_blas.size(); b++)
+        if (c->h_blas[b].nodes && b < c->blas_inner_depth.size() && c->blas_inner_depth[b] + 2 > c->cfg.stack_size) {
+            c->err = "BVH deeper than rtx_config.stack_size allows (BVH_TRAVERSAL_STACK_SIZE, Config.h:25): an inner node at depth " + std::to_string(c->blas_inner_depth[b]) + " needs " + std::to_string(c->blas_inner_depth[b] + 2) + " stack entries";
+            return RTX_ERR_LIMIT;
+        }
+    if (c->tlas_inner_depth + 2 > c->cfg.stack_size) { c->err = "TLAS deeper than rtx_config.stack_size allows (BVH_TRAVERSAL_STACK_SIZE, Config.h:25)"; return RTX_ERR_LIMIT; }
     for (size_t i = 0; i < c->h_materials.size(); i++) {
         const int t = c->h_materials[i].texture_id;
         if (t >= 0 && ((size_t)t >= c->h_tex.size() || !c->h_tex[t].texels)) { c->err = "material refers to a texture id that was never uploaded"; return RTX_ERR_STATE; }
@@ -411,12 +457,14 @@ static int alloc_queues(rtx_ctx * c, int batch_tiles) {
     if (!rc) rc = ensure(c, c->qb[k], sslots * 4); c->q.socc = (uint32_t *)c->qb[k].p; k++;
     c->q.spill = (int32_t *)c->d_spill.p;
     c->q.counters = (DevCounters *)c->d_counters.p;
+    c->q.pk_heads = (uint32_t *)c->d_pk_heads.p;
     c->q.fb_rgb = (float *)(c->ext_rgb ? c->ext_rgb : c->d_fb_rgb.p);
     c->q.fb_packed = (uint32_t *)(c->ext_packed ? c->ext_packed : c->d_fb_packed.p);
     return rc;
 }
 
-__global__ void k_begin_batch(DevCounters * ctr, uint32_t primary_slots, uint32_t closest_threads, uint32_t any_threads, int first_batch) {
+__global__ void k_begin_batch(DevCounters * ctr, uint32_t * pk_heads, uint32_t primary_slots, uint32_t closest_threads, uint32_t any_threads,
+                              uint32_t pk_waves_closest, uint32_t pk_waves_any, int first_batch) {
     // the first batch of a render call zeroes the whole counter block (stats of this call, WorkerThread.cpp:120) — done here rather than
     // with hipMemsetAsync, whose blit serialises the streams of different contexts against each other; every batch then resets the
     // queue state: the dynamic-fetch heads start behind the statically assigned first round (one ray per resident thread)
@@ -427,6 +475,10 @@ __global__ void k_begin_batch(DevCounters * ctr, uint32_t primary_slots, uint32_
         __syncthreads();
     }
     if (i <= RTX_MAX_LEVELS) { ctr->ray_count[i] = (i == 0) ? primary_slots : 0u; ctr->lit_count[i] = 0u; ctr->fetch_closest[i] = closest_threads; ctr->fetch_any[i] = any_threads; }
+    // packet-queue heads (rtx_packet.h): head c of a launch hands out packets k * 8 + c; the static first round (wave w takes packet w)
+    // has already covered k < waves / 8 of every head
+    for (int k = i; k < 2 * (RTX_MAX_LEVELS + 1) * RTX_PK_CLASSES; k += blockDim.x)
+        pk_heads[k * 32] = (k < (RTX_MAX_LEVELS + 1) * RTX_PK_CLASSES ? pk_waves_closest : pk_waves_any) / RTX_PK_CLASSES;
 }
 
 static hipEvent_t next_event(rtx_ctx * c) {
@@ -455,10 +507,14 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
     const bool count_work = (flags & RTX_RENDER_COUNT_WORK) != 0;
     const bool simple = (flags & RTX_RENDER_SIMPLE_TRACE) != 0;
     const bool cull = (flags & RTX_RENDER_CULL_DEAD_SHADOW_RAYS) != 0 && !simple && !count_work;
+    bool lane = (flags & RTX_RENDER_LANE_TRACE) != 0;
+    for (size_t b = 0; b < c->blas_packet_ok.size(); b++) if (c->h_blas[b].nodes && !c->blas_packet_ok[b]) lane = true;      // limits of the packet kernels' packed entries
+    const bool pk_closest = (flags & RTX_RENDER_PACKET_CLOSEST) != 0;      // closest-hit rays: per-lane kernel by default (see rtx.h)
+    const bool pstat = (flags & RTX_RENDER_PACKET_STATS) != 0 && !simple && !count_work && !lane;
     c->serial = (flags & RTX_RENDER_SERIAL) != 0;
 
     // stats of this call are reset by the first k_begin_batch (WorkerThread.cpp:120 zeroes them per frame)
-    if (tile_count == 0) { hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, (DevCounters *)c->d_counters.p, 0u, 0u, 0u, 1); c->stats_pending = true; return RTX_OK; }
+    if (tile_count == 0) { hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, (DevCounters *)c->d_counters.p, (uint32_t *)c->d_pk_heads.p, 0u, 0u, 0u, 8u, 8u, 1); c->stats_pending = true; return RTX_OK; }
 
     int batch_tiles = 0;
     plan_batch(c, tile_count, batch_tiles);
@@ -474,9 +530,10 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
         q.first_tile = first_tile + done * tile_stride; q.tile_stride = tile_stride; q.tile_count = n; q.primary_slots = n * 1024;
         const DevScene sc = c->scene;
         const bool plain = count_work || simple || sc.heatmap;
-        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, q.counters, (uint32_t)q.primary_slots,
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, q.counters, q.pk_heads, (uint32_t)q.primary_slots,
                            (uint32_t)((plain ? c->trace_blocks_count : c->trace_blocks_closest) * RTX_TRACE_BLOCK),
-                           (uint32_t)((plain ? c->trace_blocks_count : c->trace_blocks_any) * RTX_TRACE_BLOCK), done == 0 ? 1 : 0);
+                           (uint32_t)((plain ? c->trace_blocks_count : c->trace_blocks_any) * RTX_TRACE_BLOCK),
+                           (uint32_t)(c->pk_blocks_closest * (RTX_PK_BLOCK / RTX_WAVE)), (uint32_t)(c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE)), done == 0 ? 1 : 0);
         // Main stream: closest(d) -> shade(d) for d = 0..D.  Shadow rays depend only on shade, so in the default (fast)
         // configuration they run on a second stream: any(level 0) starts after shade(0) and overlaps the deeper levels'
         // closest/shade kernels; the shadow rays of levels 1..D are traced by ONE more launch after shade(D).  This removes
@@ -493,12 +550,27 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
             launch_timed(c, "k_heatmap", c->stream, [&] { hipLaunchKernelGGL(k_heatmap, dim3(stream_blocks), dim3(256), 0, c->stream, sc, q); });
             continue;
         }
-        for (int level = 0; level < levels; level++) {
+        // traversal kernels: packet walk (production), per-lane pair fetch (RTX_RENDER_LANE_TRACE), plain pop-and-test (SIMPLE / COUNT_WORK)
+        auto launch_closest = [&](int level) {
             launch_timed(c, "k_trace_closest", c->stream, [&] {
-                if (count_work)   hipLaunchKernelGGL((k_trace<false, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else if (simple)  hipLaunchKernelGGL((k_trace<false, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else              hipLaunchKernelGGL((k_trace_fast<false>),   dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
+                if (count_work)     hipLaunchKernelGGL((k_trace<false, true>),   dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else if (simple)    hipLaunchKernelGGL((k_trace<false, false>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
+                else if (lane || !(pk_closest || pstat)) hipLaunchKernelGGL((k_trace_fast<false>), dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
+                else if (pstat)     hipLaunchKernelGGL((k_packet<false, true>),  dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
+                else                hipLaunchKernelGGL((k_packet<false, false>), dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
             });
+        };
+        auto launch_any = [&](hipStream_t st, int lo, int hi) {
+            launch_timed(c, "k_trace_any", st, [&] {
+                if (count_work)     hipLaunchKernelGGL((k_trace<true, true>),   dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, st, sc, q, lo);
+                else if (simple)    hipLaunchKernelGGL((k_trace<true, false>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, st, sc, q, lo);
+                else if (lane)      hipLaunchKernelGGL((k_trace_fast<true>),    dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, st, sc, q, lo, hi);
+                else if (pstat)     hipLaunchKernelGGL((k_packet<true, true>),  dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, hi);
+                else                hipLaunchKernelGGL((k_packet<true, false>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, hi);
+            });
+        };
+        for (int level = 0; level < levels; level++) {
+            launch_closest(level);
             launch_timed(c, "k_shade", c->stream, [&] {
                 if (count_work) hipLaunchKernelGGL((k_shade<true, false>),  dim3(shade_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
                 else if (cull)  hipLaunchKernelGGL((k_shade<false, true>),  dim3(shade_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
@@ -509,25 +581,17 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
                 if (level == 0) {
                     hipEventRecord(c->ev_shade0, c->stream);
                     hipStreamWaitEvent(c->any_stream, c->ev_shade0, 0);
-                    launch_timed(c, "k_trace_any", c->any_stream, [&] {
-                        hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 0, 0); });
+                    launch_any(c->any_stream, 0, 0);
                 }
                 if (level == levels - 1 && levels > 1) {
                     hipEventRecord(c->ev_shade_last, c->stream);
                     hipStreamWaitEvent(c->any_stream, c->ev_shade_last, 0);
-                    launch_timed(c, "k_trace_any", c->any_stream, [&] {
-                        hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->any_stream, sc, q, 1, levels - 1); });
+                    launch_any(c->any_stream, 1, levels - 1);
                 }
             } else if (merged) {
-                // shadow rays only feed k_resolve: all levels' shadow rays are traced by ONE launch after the last shade (three fewer
-                // persistent-launch tails per frame)
-                if (level == levels - 1) launch_timed(c, "k_trace_any", c->stream, [&] {
-                    hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, 0, levels - 1); });
-            } else launch_timed(c, "k_trace_any", c->stream, [&] {
-                if (count_work)   hipLaunchKernelGGL((k_trace<true, true>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else if (simple)  hipLaunchKernelGGL((k_trace<true, false>), dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else              hipLaunchKernelGGL((k_trace_fast<true>),   dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
-            });
+                // shadow rays only feed k_resolve: all levels' shadow rays are traced by ONE launch after the last shade
+                if (level == levels - 1) launch_any(c->stream, 0, levels - 1);
+            } else launch_any(c->stream, level, level);
         }
         if (overlap) { hipEventRecord(c->ev_any_done, c->any_stream); hipStreamWaitEvent(c->stream, c->ev_any_done, 0); }
         for (int level = levels - 1; level >= 0; level--)
@@ -555,7 +619,7 @@ extern "C" int rtx_get_stats(rtx_ctx * c, rtx_stats * stats, rtx_work_counters *
         c->stats_acc.num_primary_rays = h.stats[0]; c->stats_acc.num_shadow_rays = h.stats[1];
         c->stats_acc.num_reflection_rays = h.stats[2]; c->stats_acc.num_refraction_rays = h.stats[3];
         memset(&c->work_acc, 0, sizeof(c->work_acc));
-        memcpy(&c->work_acc, h.work, sizeof(uint64_t) * 15);
+        memcpy(&c->work_acc, h.work, sizeof(uint64_t) * 20);
         c->err_flags_acc = h.error_flags;
         c->stats_pending = false;
     }

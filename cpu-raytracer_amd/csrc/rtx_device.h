@@ -34,7 +34,8 @@
 #define NF_ENTER    32
 
 struct DevBlas {
-    const float4 *            nodes;      // 2 x float4 per node: (min.xyz, left_or_first) (max.xyz, count)
+    const float4 *            nodes;      // 2 x float4 per node: (min.xyz, left_or_first) (max.xyz, count)   [per-lane kernels, rtx_trace.h]
+    const float4 *            pk_nodes;   // 2 x float4 per node: (min.x, min.y, max.x, max.y) (min.z, max.z, left_or_first, count)   [packet kernels, rtx_packet.h]
     const float4 *            tri_hot;    // RTX_TRI_STRIDE x float4 per triangle: (p0, -) (e1, -) (e2, -) (padding)
     const rtx_triangle_cold * tri_cold;   // reference layout, 64 B
     int32_t node_count, tri_count, material_offset, pad;
@@ -80,6 +81,7 @@ struct DevScene {
     const float *         ewa_table;
 
     const float4 *        tlas_nodes;   int32_t tlas_node_count;
+    const float4 *        pk_tlas_nodes;                       // the TLAS in the packet kernels' node layout
     const int32_t *       tlas_indices; int32_t tlas_index_count;
     const rtx_instance *  instances;    int32_t instance_count;
     const rtx_sphere *    spheres;      int32_t sphere_count;
@@ -122,7 +124,9 @@ struct DevQueues {
 
     int32_t *     spill;          // traversal stack spill, 3 regions of [(entry - RTX_LDS_STACK) * spill_threads + thread]: closest entries, closest keys, shadow entries
     int32_t       spill_threads;
+    int32_t       pk_defer_t0;    // hybrid any-hit walk: nodes wanted by at most this many lanes (+ walk length / 8) go to the lanes' private stacks
     DevCounters * counters;
+    uint32_t *    pk_heads;       // packet-queue heads of the packet kernels: [closest | any][level][8 heads], 128 bytes apart (rtx_packet.h)
     float *       fb_rgb;         // W*H*3
     uint32_t *    fb_packed;      // W*H
 };

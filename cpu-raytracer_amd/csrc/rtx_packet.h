@@ -1,0 +1,983 @@
+// rtx_packet.h — wave-packet traversal: the production closest-hit and any-hit kernels.
+//
+// A wavefront walks the BVH for the 64 rays of one PACKET together (the reference's own idea — Raytracer::render_tile traces
+// SIMD_LANE_SIZE-wide packets, BottomLevelBVH.cpp:355-437 — at the width of a CDNA4 wave):
+//
+//   * ONE traversal stack per wave holding (node, 64-bit lane mask).  A lane is in a node's mask iff every box on the chain from
+//     the root passed THAT lane's own slab test — exactly the set of nodes the reference's per-ray loop would pop and pass for
+//     that ray (SIMD_LANE_SIZE 1), so each lane tests exactly the triangles the reference tests for it.  The stack lives in six
+//     VGPRs (lane i = entry i, v_writelane / v_readlane): no LDS, no memory latency on push / pop.
+//   * node pairs and triangles are wave-uniform: they are fetched with SCALAR loads (s_load_dwordx8/x16 through the scalar data
+//     cache) into SGPRs and fed to the VALU as scalar operands.  No per-lane gather, no per-lane stack: the resource the per-lane
+//     kernels of rtx_trace.h are bound by (the CU's divergent-gather rate) is not used at all.
+//   * masks are v_cmp results combined with SALU; control flow is wave-uniform (s_cbranch), there is no divergence.
+//   * the slab test is written for the packed-fp32 VALU (v_pk_add_f32 / v_pk_mul_f32): the device node record is
+//     (min.x, min.y, max.x, max.y) (min.z, max.z, first, count), so each SGPR pair is one packed operand.
+//
+// Exactness (the parity contract is bit-identical hits):
+//   any-hit      the result "some triangle in a leaf this ray reaches is hit" does not depend on visiting order; per-lane masks keep
+//                the reached-leaf set identical, so occlusion flags equal the reference's.
+//   closest-hit  the reference's result depends on ORDER (equal-t ties: first found wins; culling against the closest distance so
+//                far).  Lanes are independent, and a lane's own order is preserved as long as every inner node it visits is
+//                expanded in that lane's near/far order.  BVHNode::should_visit_left_first (BVHNode.h:30-40) depends only on the
+//                sign of one direction component, so at a node where the lanes of the mask disagree the mask is SPLIT: the lanes
+//                that want the other order are parked on the stack as a "pretested" entry for the same node and walk its subtree
+//                afterwards.  The far child is pushed with the lanes that pass now and re-tested at pop time against each lane's
+//                then-current closest distance — the reference's pop-time test (slab test monotone in the distance: a lane that
+//                fails now would fail later).
+//   NaN          min/max are `a<b?a:b` in the reference (NaN -> b).  A slab test can only produce a NaN as 0 * inf, i.e. when an
+//                inverse direction component is infinite; packets whose lanes all have finite inverse directions run the FAST
+//                variant (v_min/v_max/v_min3/v_max3, identical on non-NaN operands), all others the reference-form variant.
+//   stack size   the reference's per-BVH stack (BVH_TRAVERSAL_STACK_SIZE, Config.h:25) holds one pending far sibling per ancestor
+//                entered through its near child and overflows when an inner node is expanded with size - 1 or more pending.  That
+//                count is wave-uniform here (`depth`), travels with the stack entries, and raises ERR_STACK_OVERFLOW at exactly the
+//                configured rtx_config.stack_size.
+#pragma once
+#include "rtx_math.h"
+#include "rtx_device.h"
+#include "rtx_trace.h"
+
+#define RTX_PK_BLOCK    256          // 4 independent waves per workgroup
+#define RTX_PK_STACK    64           // packet stack entries per wave = lanes of the stack VGPRs
+#define RTX_PK_CLASSES  8            // packet-queue heads per launch (packet k belongs to head k % 8): spreads the fetch atomics over 8 addresses
+#ifndef RTX_PK_WAVES_ANY
+#define RTX_PK_WAVES_ANY 5           // __launch_bounds__ min waves per SIMD (93 VGPRs unconstrained; forcing 8 waves spills 26 dwords per lane)
+#endif
+#ifndef RTX_PK_WAVES_CLOSEST
+#define RTX_PK_WAVES_CLOSEST 4
+#endif
+
+// constant address space + wave-uniform index = scalar load
+typedef const __attribute__((address_space(4))) rtx_f4v * rtx_cptr;
+typedef float rtx_f2v __attribute__((ext_vector_type(2)));
+RTX_D int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+RTX_D unsigned long long rfl64(unsigned long long v) { return ((unsigned long long)(uint32_t)rfl((int)(uint32_t)(v >> 32)) << 32) | (unsigned long long)(uint32_t)rfl((int)(uint32_t)v); }
+RTX_D rtx_cptr pk_cptr(const void * p) {          // pointers out of device tables arrive in VGPRs: make them wave-uniform (SGPR pair)
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned long long u = ((unsigned long long)(uint32_t)rfl((int)(uint32_t)(a >> 32)) << 32) | (unsigned long long)(uint32_t)rfl((int)(uint32_t)a);
+    return (rtx_cptr)u;
+}
+RTX_D float4 sld(rtx_cptr p, int i) { const rtx_f4v v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+
+// v_min / v_max without the canonicalisation clang adds for fminf / fmaxf (operands here are never NaN: FAST packets only)
+RTX_D float pk_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RTX_D float pk_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RTX_D float pk_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RTX_D float pk_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RTX_D float pk_max_s(float s, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(s), "v"(b)); return r; }
+
+#define PK_FLAG_ITER      0x40000000      // df: entry iterates over the instances of a TLAS leaf (a = next leaf slot, b = remaining)
+#define PK_FLAG_PRETESTED 0x20000000      // df: lanes of the mask already passed this node's slab test (sign split)
+
+// packet-walk statistics (RTX_RENDER_PACKET_STATS), rtx_work_counters::reserved order
+enum { PKS_PACKETS, PKS_PAIR_STEPS, PKS_TRI_STEPS, PKS_PAIR_LANES, PKS_TRI_LANES };
+
+struct PkRay {                       // per lane: the ray in the space being walked, paired for the packed-fp32 VALU
+    rtx_f2v o_xy, o_zz, i_xy, i_zz;  // origin (x, y) (z, z), inverse direction (x, y) (z, z)
+    v3 d;
+    float tcur;                      // closest distance so far (any-hit: the constant maximum distance)
+};
+RTX_D void pk_set_ray(PkRay & r, v3 o, v3 d, v3 inv) {
+    r.o_xy = rtx_f2v{ o.x, o.y }; r.o_zz = rtx_f2v{ o.z, o.z };
+    r.i_xy = rtx_f2v{ inv.x, inv.y }; r.i_zz = rtx_f2v{ inv.z, inv.z };
+    r.d = d;
+}
+
+// AABB::intersect (AABB.cpp:38-52) on a packet node record q0 = (min.x, min.y, max.x, max.y), q1 = (min.z, max.z, -, -)
+template <bool FAST>
+RTX_D bool pk_slab(float4 q0, float4 q1, const PkRay & r) {
+    const rtx_f2v t0xy = (rtx_f2v{ q0.x, q0.y } - r.o_xy) * r.i_xy;      // (t0.x, t0.y)
+    const rtx_f2v t1xy = (rtx_f2v{ q0.z, q0.w } - r.o_xy) * r.i_xy;      // (t1.x, t1.y)
+    const rtx_f2v tz   = (rtx_f2v{ q1.x, q1.y } - r.o_zz) * r.i_zz;      // (t0.z, t1.z)
+    if (FAST) {
+        const float t_near = pk_max_s(RAY_EPSILON, pk_max3(pk_min(t0xy.x, t1xy.x), pk_min(t0xy.y, t1xy.y), pk_min(tz.x, tz.y)));
+        const float t_far  = pk_min(r.tcur, pk_min3(pk_max(t0xy.x, t1xy.x), pk_max(t0xy.y, t1xy.y), pk_max(tz.x, tz.y)));
+        return t_near < t_far;
+    }
+    const float tminx = fmin_ref(t0xy.x, t1xy.x), tminy = fmin_ref(t0xy.y, t1xy.y), tminz = fmin_ref(tz.x, tz.y);
+    const float tmaxx = fmax_ref(t0xy.x, t1xy.x), tmaxy = fmax_ref(t0xy.y, t1xy.y), tmaxz = fmax_ref(tz.x, tz.y);
+    const float t_near = fmax_ref(fmax_ref(RAY_EPSILON, tminx), fmax_ref(tminy, tminz));
+    const float t_far  = fmin_ref(fmin_ref(r.tcur, tmaxx), fmin_ref(tmaxy, tmaxz));
+    return t_near < t_far;
+}
+
+#ifdef RTX_PK_PROF
+#define PK_T0() const unsigned long long pk_t0_ = __builtin_amdgcn_s_memtime()
+#define PK_T1(slot) do { W.prof[slot] += __builtin_amdgcn_s_memtime() - pk_t0_; W.prof[slot + 5]++; } while (0)
+#else
+#define PK_T0() do {} while (0)
+#define PK_T1(slot) do {} while (0)
+#endif
+struct PkWalk {                      // everything a packet walk carries; wave-uniform unless noted
+    rtx_cptr tlas, nodes, tris;
+    int sp, floor_sp, cur_inst, depth;
+    int cur_idx, cur_first, cur_cnt;
+    unsigned long long m, alive;
+    int st_a, st_b, st_mlo, st_mhi, st_idx, st_df;      // per lane: the stack, lane i = entry i
+    PkRay ray;                                           // per lane
+    bool valid, occluded;                                // per lane
+    int best_prim, best_tri; float best_u, best_v;       // per lane (closest-hit)
+    int psp;                                             // per lane: entries on the lane's PRIVATE stack (hybrid any-hit walk)
+    int pk_steps;                                        // steps of the current packet walk (the deferral threshold grows with it)
+    uint32_t err;
+    unsigned long long st_pairs, st_tris, st_pair_lanes, st_tri_lanes;
+#ifdef RTX_PK_PROF
+    unsigned long long prof[10];      // cycles: 0 setup, 1 descend, 2 leaf, 3 pop, 4 results; 5..9 their counts
+#endif
+};
+
+// v_writelane_b32: hipcc declares no __builtin_amdgcn_writelane, so the LLVM intrinsic is bound by name
+extern "C" __device__ int rtx_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+// Push: the (wave-uniform) fields go into lane `sp` of the stack VGPRs
+template <bool ANY>
+RTX_D void pk_push(PkWalk & W, int a, int b, unsigned long long mask, int idx, int df) {
+    if (W.sp >= RTX_PK_STACK) { W.err = 1; return; }
+    W.st_a   = rtx_writelane(a, W.sp, W.st_a);
+    W.st_b   = rtx_writelane(b, W.sp, W.st_b);
+    W.st_mlo = rtx_writelane((int)(uint32_t)mask, W.sp, W.st_mlo);
+    W.st_mhi = rtx_writelane((int)(uint32_t)(mask >> 32), W.sp, W.st_mhi);
+    W.st_df  = rtx_writelane(df, W.sp, W.st_df);
+    if (!ANY) W.st_idx = rtx_writelane(idx, W.sp, W.st_idx);      // node index: only the closest-hit pop-time re-test needs it
+    W.sp++;
+}
+
+// ---- the descend loop, hand-scheduled --------------------------------------------------------------------------------------
+// From an inner node (cur_first, cur_cnt, m != 0) walk down — child-pair fetch, two slab tests, near / far choice, push of the far
+// child — until a leaf is reached (returns with the leaf in cur_* and its mask in m) or no lane is left (m == 0).  This is the inner
+// loop of the FAST walk (finite inverse directions: v_min / v_max semantics equal the reference's on non-NaN operands) written as
+// one asm block, because the compiler keeps the wave-uniform state of this loop in VGPRs (selects through v_cndmask, address
+// arithmetic on the VALU, copies of the stack registers at every join): 124 VALU instructions per step compiled vs 34 + 5 here.
+//   SGPR temporaries s[64:95] (child pair in s[64:79]), VGPR temporaries v[84:93]; both are declared as clobbers.
+//   Hazards (gfx940/950 table): every VALU -> VALU dependency is through VGPRs (interlocked); VCC written by v_cmp is read by SALU
+//   only (interlocked); M0 is written by SALU before v_writelane (no wait state required, one s_nop kept); no trans ops, no DPP.
+#define PK_ASM_SLAB(X0, X1, X2, X3, X4, X5, MASK)                                                                                   \
+    "v_pk_add_f32 v[84:85], s[" #X0 ":" #X1 "], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                              \
+    "v_pk_add_f32 v[86:87], s[" #X2 ":" #X3 "], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                              \
+    "v_pk_add_f32 v[88:89], s[" #X4 ":" #X5 "], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                              \
+    "v_pk_mul_f32 v[84:85], %[ixy], v[84:85]\n\t"                                                                                   \
+    "v_pk_mul_f32 v[86:87], %[ixy], v[86:87]\n\t"                                                                                   \
+    "v_pk_mul_f32 v[88:89], %[izz], v[88:89]\n\t"                                                                                   \
+    "v_min_f32 v90, v84, v86\n\t"                                                                                                   \
+    "v_max_f32 v84, v84, v86\n\t"                                                                                                   \
+    "v_min_f32 v91, v85, v87\n\t"                                                                                                   \
+    "v_max_f32 v85, v85, v87\n\t"                                                                                                   \
+    "v_min_f32 v86, v88, v89\n\t"                                                                                                   \
+    "v_max_f32 v87, v88, v89\n\t"                                                                                                   \
+    "v_max3_f32 v90, v90, v91, v86\n\t"                                                                                             \
+    "v_min3_f32 v84, v84, v85, v87\n\t"                                                                                             \
+    "v_max_f32 v90, %[eps], v90\n\t"                                                                                                \
+    "v_min_f32 v84, %[tcur], v84\n\t"                                                                                               \
+    "v_cmp_lt_f32 vcc, v90, v84\n\t"                                                                                                \
+    "s_and_b64 " MASK ", vcc, %[m]\n\t"
+
+template <bool ANY>
+RTX_D void pk_descend(PkWalk & W, int stack_size, int ordered) {
+    // "s" operands must really be SGPRs: whatever the compiler did with the wave-uniform state, pin it here
+    W.cur_first = rfl(W.cur_first); W.cur_cnt = rfl(W.cur_cnt); W.cur_idx = rfl(W.cur_idx); W.m = rfl64(W.m); W.sp = rfl(W.sp);
+    W.depth = rfl(W.depth); W.err = (uint32_t)rfl((int)W.err); stack_size = rfl(stack_size); ordered = rfl(ordered);
+    const unsigned long long posx = __ballot(W.ray.d.x > 0.0f), posy = __ballot(W.ray.d.y > 0.0f), posz = __ballot(W.ray.d.z > 0.0f);
+    const float eps = RAY_EPSILON;
+    const unsigned long long nodes = rfl64((unsigned long long)W.nodes);
+    if (ANY) {
+        asm volatile(
+            "s_mov_b64 s[94:95], %[nodes]\n\t"
+            "PKA_TOP_%=:\n\t"
+            // reference stack emulation: `depth` pending + 2 pushed
+            "s_add_i32 s90, %[depth], 2\n\t"
+            "s_cmp_gt_i32 s90, %[ssz]\n\t"
+            "s_cselect_b32 %[err], 1, %[err]\n\t"
+            // child pair: 64 bytes at nodes + first * 32
+            "s_mov_b32 s92, %[first]\n\t"
+            "s_mov_b32 s93, 0\n\t"
+            "s_lshl_b64 s[92:93], s[92:93], 5\n\t"
+            "s_add_u32 s92, s92, s94\n\t"
+            "s_addc_u32 s93, s93, s95\n\t"
+            "s_load_dwordx16 s[64:79], s[92:93], 0x0\n\t"
+            // order (any-hit: any order is exact; the first lane's): left_first = !ordered | axis == 0 | pos_axis[first lane of m]
+            "s_lshr_b32 s90, %[cnt], 30\n\t"
+            "s_mov_b64 s[86:87], %[posx]\n\t"
+            "s_cmp_eq_u32 s90, 2\n\t"
+            "s_cselect_b64 s[86:87], %[posy], s[86:87]\n\t"
+            "s_cmp_eq_u32 s90, 3\n\t"
+            "s_cselect_b64 s[86:87], %[posz], s[86:87]\n\t"
+            "s_ff1_i32_b64 s91, %[m]\n\t"
+            "s_bitcmp1_b64 s[86:87], s91\n\t"
+            "s_cselect_b32 s91, 1, 0\n\t"
+            "s_cmp_eq_u32 s90, 0\n\t"
+            "s_cselect_b32 s91, 1, s91\n\t"
+            "s_cmp_eq_u32 %[ordered], 0\n\t"
+            "s_cselect_b32 s91, 1, s91\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            PK_ASM_SLAB(64, 65, 66, 67, 68, 69, "s[82:83]")
+            PK_ASM_SLAB(72, 73, 74, 75, 76, 77, "s[84:85]")
+            // near / far
+            "s_cmp_lg_u32 s91, 0\n\t"
+            "s_cselect_b64 s[86:87], s[82:83], s[84:85]\n\t"
+            "s_cselect_b64 s[88:89], s[84:85], s[82:83]\n\t"
+            "s_cselect_b32 s80, s70, s78\n\t"
+            "s_cselect_b32 s81, s71, s79\n\t"
+            "s_cselect_b32 s92, s78, s70\n\t"
+            "s_cselect_b32 s93, s79, s71\n\t"
+            "s_cmp_eq_u64 s[86:87], 0\n\t"
+            "s_cbranch_scc1 PKA_NONEAR_%=\n\t"
+            "s_cmp_eq_u64 s[88:89], 0\n\t"
+            "s_cbranch_scc1 PKA_NOFAR_%=\n\t"
+            "s_cmp_ge_i32 %[sp], 64\n\t"
+            "s_cbranch_scc1 PKA_OVER_%=\n\t"
+            "s_mov_b32 m0, %[sp]\n\t"
+            "s_nop 0\n\t"
+            "v_writelane_b32 %[sta], s92, m0\n\t"
+            "v_writelane_b32 %[stb], s93, m0\n\t"
+            "v_writelane_b32 %[stmlo], s88, m0\n\t"
+            "v_writelane_b32 %[stmhi], s89, m0\n\t"
+            "v_writelane_b32 %[stdf], %[depth], m0\n\t"
+            "s_add_i32 %[sp], %[sp], 1\n\t"
+            "PKA_NOFAR_%=:\n\t"
+            "s_mov_b32 %[first], s80\n\t"
+            "s_mov_b32 %[cnt], s81\n\t"
+            "s_mov_b64 %[m], s[86:87]\n\t"
+            "s_add_i32 %[depth], %[depth], 1\n\t"
+            "s_branch PKA_CHECK_%=\n\t"
+            "PKA_OVER_%=:\n\t"
+            "s_mov_b32 %[err], 1\n\t"
+            "s_branch PKA_NOFAR_%=\n\t"
+            "PKA_NONEAR_%=:\n\t"
+            "s_mov_b32 %[first], s92\n\t"
+            "s_mov_b32 %[cnt], s93\n\t"
+            "s_mov_b64 %[m], s[88:89]\n\t"
+            "s_cmp_eq_u64 s[88:89], 0\n\t"
+            "s_cbranch_scc1 PKA_END_%=\n\t"
+            "PKA_CHECK_%=:\n\t"
+            "s_and_b32 s90, %[cnt], 0x3fffffff\n\t"
+            "s_cmp_eq_u32 s90, 0\n\t"
+            "s_cbranch_scc1 PKA_TOP_%=\n\t"
+            "PKA_END_%=:\n\t"
+            : [first] "+&s"(W.cur_first), [cnt] "+&s"(W.cur_cnt), [m] "+&s"(W.m), [sp] "+&s"(W.sp), [depth] "+&s"(W.depth), [err] "+&s"(W.err),
+              [sta] "+&v"(W.st_a), [stb] "+&v"(W.st_b), [stmlo] "+&v"(W.st_mlo), [stmhi] "+&v"(W.st_mhi), [stdf] "+&v"(W.st_df)
+            : [nodes] "s"(nodes), [oxy] "v"(W.ray.o_xy), [ozz] "v"(W.ray.o_zz), [ixy] "v"(W.ray.i_xy), [izz] "v"(W.ray.i_zz), [tcur] "v"(W.ray.tcur),
+              [posx] "s"(posx), [posy] "s"(posy), [posz] "s"(posz), [ssz] "s"(stack_size), [eps] "s"(eps), [ordered] "s"(ordered)
+            : "vcc", "scc", "m0",
+              "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
+              "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
+              "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+    } else {
+        asm volatile(
+            "s_mov_b64 s[94:95], %[nodes]\n\t"
+            "PKC_TOP_%=:\n\t"
+            "s_add_i32 s90, %[depth], 2\n\t"
+            "s_cmp_gt_i32 s90, %[ssz]\n\t"
+            "s_cselect_b32 %[err], 1, %[err]\n\t"
+            "s_mov_b32 s92, %[first]\n\t"
+            "s_mov_b32 s93, 0\n\t"
+            "s_lshl_b64 s[92:93], s[92:93], 5\n\t"
+            "s_add_u32 s92, s92, s94\n\t"
+            "s_addc_u32 s93, s93, s95\n\t"
+            "s_load_dwordx16 s[64:79], s[92:93], 0x0\n\t"
+            // order (closest hit): every lane must see ITS OWN near / far order; lanes that disagree are parked on this node
+            "s_mov_b32 s91, 1\n\t"
+            "s_cmp_eq_u32 %[ordered], 0\n\t"
+            "s_cbranch_scc1 PKC_ORD_%=\n\t"
+            "s_lshr_b32 s90, %[cnt], 30\n\t"
+            "s_cmp_eq_u32 s90, 0\n\t"
+            "s_cbranch_scc1 PKC_ORD_%=\n\t"
+            "s_mov_b64 s[86:87], %[posx]\n\t"
+            "s_cmp_eq_u32 s90, 2\n\t"
+            "s_cselect_b64 s[86:87], %[posy], s[86:87]\n\t"
+            "s_cmp_eq_u32 s90, 3\n\t"
+            "s_cselect_b64 s[86:87], %[posz], s[86:87]\n\t"
+            "s_and_b64 s[86:87], s[86:87], %[m]\n\t"
+            "s_cmp_eq_u64 s[86:87], 0\n\t"
+            "s_cselect_b32 s91, 0, 1\n\t"
+            "s_cbranch_scc1 PKC_ORD_%=\n\t"
+            "s_cmp_eq_u64 s[86:87], %[m]\n\t"
+            "s_cbranch_scc1 PKC_ORD_%=\n\t"
+            // split: park (node, m & ~pos) as a pretested entry, continue with the left-first lanes
+            "s_andn2_b64 s[88:89], %[m], s[86:87]\n\t"
+            "s_mov_b64 %[m], s[86:87]\n\t"
+            "s_cmp_ge_i32 %[sp], 64\n\t"
+            "s_cselect_b32 %[err], 1, %[err]\n\t"
+            "s_cbranch_scc1 PKC_ORD_%=\n\t"
+            "s_mov_b32 m0, %[sp]\n\t"
+            "s_or_b32 s90, %[depth], 0x20000000\n\t"
+            "v_writelane_b32 %[sta], %[first], m0\n\t"
+            "v_writelane_b32 %[stb], %[cnt], m0\n\t"
+            "v_writelane_b32 %[stmlo], s88, m0\n\t"
+            "v_writelane_b32 %[stmhi], s89, m0\n\t"
+            "v_writelane_b32 %[stdf], s90, m0\n\t"
+            "v_writelane_b32 %[stidx], %[idx], m0\n\t"
+            "s_add_i32 %[sp], %[sp], 1\n\t"
+            "PKC_ORD_%=:\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            PK_ASM_SLAB(64, 65, 66, 67, 68, 69, "s[82:83]")
+            PK_ASM_SLAB(72, 73, 74, 75, 76, 77, "s[84:85]")
+            // near / far (left child index = first, right = first + 1)
+            "s_add_i32 s90, %[first], 1\n\t"
+            "s_cmp_lg_u32 s91, 0\n\t"
+            "s_cselect_b64 s[86:87], s[82:83], s[84:85]\n\t"
+            "s_cselect_b64 s[88:89], s[84:85], s[82:83]\n\t"
+            "s_cselect_b32 s80, s70, s78\n\t"
+            "s_cselect_b32 s81, s71, s79\n\t"
+            "s_cselect_b32 s92, s78, s70\n\t"
+            "s_cselect_b32 s93, s79, s71\n\t"
+            "s_cselect_b32 s82, %[first], s90\n\t"          // near index
+            "s_cselect_b32 s83, s90, %[first]\n\t"          // far index
+            "s_cmp_eq_u64 s[86:87], 0\n\t"
+            "s_cbranch_scc1 PKC_NONEAR_%=\n\t"
+            "s_cmp_eq_u64 s[88:89], 0\n\t"
+            "s_cbranch_scc1 PKC_NOFAR_%=\n\t"
+            "s_cmp_ge_i32 %[sp], 64\n\t"
+            "s_cbranch_scc1 PKC_OVER_%=\n\t"
+            "s_mov_b32 m0, %[sp]\n\t"
+            "s_nop 0\n\t"
+            "v_writelane_b32 %[sta], s92, m0\n\t"
+            "v_writelane_b32 %[stb], s93, m0\n\t"
+            "v_writelane_b32 %[stmlo], s88, m0\n\t"
+            "v_writelane_b32 %[stmhi], s89, m0\n\t"
+            "v_writelane_b32 %[stdf], %[depth], m0\n\t"
+            "v_writelane_b32 %[stidx], s83, m0\n\t"
+            "s_add_i32 %[sp], %[sp], 1\n\t"
+            "PKC_NOFAR_%=:\n\t"
+            "s_mov_b32 %[first], s80\n\t"
+            "s_mov_b32 %[cnt], s81\n\t"
+            "s_mov_b32 %[idx], s82\n\t"
+            "s_mov_b64 %[m], s[86:87]\n\t"
+            "s_add_i32 %[depth], %[depth], 1\n\t"
+            "s_branch PKC_CHECK_%=\n\t"
+            "PKC_OVER_%=:\n\t"
+            "s_mov_b32 %[err], 1\n\t"
+            "s_branch PKC_NOFAR_%=\n\t"
+            "PKC_NONEAR_%=:\n\t"
+            "s_mov_b32 %[first], s92\n\t"
+            "s_mov_b32 %[cnt], s93\n\t"
+            "s_mov_b32 %[idx], s83\n\t"
+            "s_mov_b64 %[m], s[88:89]\n\t"
+            "s_cmp_eq_u64 s[88:89], 0\n\t"
+            "s_cbranch_scc1 PKC_END_%=\n\t"
+            "PKC_CHECK_%=:\n\t"
+            "s_and_b32 s90, %[cnt], 0x3fffffff\n\t"
+            "s_cmp_eq_u32 s90, 0\n\t"
+            "s_cbranch_scc1 PKC_TOP_%=\n\t"
+            "PKC_END_%=:\n\t"
+            : [first] "+&s"(W.cur_first), [cnt] "+&s"(W.cur_cnt), [idx] "+&s"(W.cur_idx), [m] "+&s"(W.m), [sp] "+&s"(W.sp), [depth] "+&s"(W.depth), [err] "+&s"(W.err),
+              [sta] "+&v"(W.st_a), [stb] "+&v"(W.st_b), [stmlo] "+&v"(W.st_mlo), [stmhi] "+&v"(W.st_mhi), [stdf] "+&v"(W.st_df), [stidx] "+&v"(W.st_idx)
+            : [nodes] "s"(nodes), [oxy] "v"(W.ray.o_xy), [ozz] "v"(W.ray.o_zz), [ixy] "v"(W.ray.i_xy), [izz] "v"(W.ray.i_zz), [tcur] "v"(W.ray.tcur),
+              [posx] "s"(posx), [posy] "s"(posy), [posz] "s"(posz), [ssz] "s"(stack_size), [eps] "s"(eps), [ordered] "s"(ordered)
+            : "vcc", "scc", "m0",
+              "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
+              "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
+              "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+    }
+}
+
+// ---- the whole any-hit walk of one BLAS, hand-scheduled ------------------------------------------------------------------------
+// BottomLevelBVH::intersect (BottomLevelBVH.cpp:398-437) for the lanes of W.m, from the node in W.cur_* until the packet stack is back
+// at W.floor_sp or no lane is alive: inner nodes (child-pair fetch, two slab tests, push of the right child), leaves
+// (triangle_intersect, BottomLevelBVH.cpp:311-346, with the triangle in SGPRs) and pops in ONE asm block.  Any-hit results do not
+// depend on the visiting order, so the left child is always walked first (no order logic at all).  Occlusion is pure mask
+// arithmetic: a lane that is hit leaves W.alive (the caller derives the per-lane flag from the masks).
+//   stack entry: a = first, b = count | depth << 16 (leaf counts < 65536 and node / triangle offsets < 2^31 are checked at upload)
+//   SGPRs: s[64:79] child pair / triangle, s[80:83] child masks, s[84:93] temporaries, s[94:97] node and triangle base addresses,
+//   s98/s99 triangle loop; VGPRs: v[84:91] slab pairs / temporaries, the rest are compiler-allocated operands.
+//   Instruction budget per inner step: 34 VALU (+4 v_writelane on a push), 16-24 SALU.
+//   Hazards (gfx940/950): v_rcp_f32 (trans) result is used two instructions later; v_div_scale writes VCC four instructions before
+//   v_div_fmas reads it; SGPRs written by v_cmp are read by SALU only; v_readlane results are consumed by SALU / SMEM (interlocked).
+RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, int defer_t0) {
+    W.cur_first = rfl(W.cur_first); W.cur_cnt = rfl(W.cur_cnt); W.m = rfl64(W.m); W.alive = rfl64(W.alive); W.sp = rfl(W.sp);
+    int depth = rfl(W.depth), maxd = -1, err = 0, steps = rfl(W.pk_steps);
+    const int floor_sp = rfl(W.floor_sp);
+    defer_t0 = rfl(defer_t0);
+    const float eps = RAY_EPSILON;
+    const unsigned long long nodes = rfl64((unsigned long long)W.nodes), tris = rfl64((unsigned long long)W.tris);
+    float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;          // triangle-test temporaries
+    asm volatile(
+        "s_mov_b64 s[94:95], %[nodes]\n\t"
+        "s_mov_b64 s[96:97], %[tris]\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 PKB_POP_%=\n\t"
+        "PKB_DISPATCH_%=:\n\t"
+        // hybrid: a node wanted by few lanes is handed to those lanes' private stacks (walked per lane after the packet walk);
+        // the threshold grows with the length of the walk, so a packet that turns out incoherent converts itself to per-lane work
+        "s_add_i32 %[steps], %[steps], 1\n\t"
+        "s_bcnt1_i32_b64 s89, %[m]\n\t"
+        "s_lshr_b32 s90, %[steps], 3\n\t"
+        "s_add_i32 s90, s90, %[t0d]\n\t"
+        "s_cmp_le_u32 s89, s90\n\t"
+        "s_cbranch_scc1 PKB_DEFER_%=\n\t"
+        "PKB_NODEFER_%=:\n\t"
+        "s_and_b32 s88, %[cnt], 0xffff\n\t"
+        "s_cmp_lg_u32 s88, 0\n\t"
+        "s_cbranch_scc1 PKB_LEAF_%=\n\t"
+        // ---------------- inner node ----------------
+        "PKB_INNER_%=:\n\t"
+        "s_lshl_b32 s88, %[first], 5\n\t"
+        "s_load_dwordx16 s[64:79], s[94:95], s88\n\t"
+        "s_max_i32 %[maxd], %[maxd], %[depth]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        PK_ASM_SLAB(64, 65, 66, 67, 68, 69, "s[80:81]")
+        PK_ASM_SLAB(72, 73, 74, 75, 76, 77, "s[82:83]")
+        "s_cmp_lg_u64 s[80:81], 0\n\t"
+        "s_cbranch_scc0 PKB_NOLEFT_%=\n\t"
+        "s_cmp_lg_u64 s[82:83], 0\n\t"
+        "s_cbranch_scc0 PKB_GOLEFT_%=\n\t"
+        // push the right child (popped with `depth` entries pending)
+        "s_cmp_ge_i32 %[sp], 64\n\t"
+        "s_cbranch_scc1 PKB_OVER_%=\n\t"
+        "s_lshl_b32 s88, %[depth], 16\n\t"
+        "s_or_b32 s88, s88, s79\n\t"
+        "s_mov_b32 m0, %[sp]\n\t"
+        "s_add_i32 %[sp], %[sp], 1\n\t"
+        "v_writelane_b32 %[sta], s78, m0\n\t"
+        "v_writelane_b32 %[stb], s88, m0\n\t"
+        "v_writelane_b32 %[stmlo], s82, m0\n\t"
+        "v_writelane_b32 %[stmhi], s83, m0\n\t"
+        "PKB_GOLEFT_%=:\n\t"
+        "s_mov_b32 %[first], s70\n\t"
+        "s_mov_b32 %[cnt], s71\n\t"
+        "s_mov_b64 %[m], s[80:81]\n\t"
+        "s_add_i32 %[depth], %[depth], 1\n\t"
+        "s_branch PKB_DISPATCH_%=\n\t"
+        "PKB_OVER_%=:\n\t"
+        "s_mov_b32 %[err], 1\n\t"
+        "s_branch PKB_GOLEFT_%=\n\t"
+        "PKB_NOLEFT_%=:\n\t"
+        "s_cmp_lg_u64 s[82:83], 0\n\t"
+        "s_cbranch_scc0 PKB_POP_%=\n\t"
+        "s_mov_b32 %[first], s78\n\t"
+        "s_mov_b32 %[cnt], s79\n\t"
+        "s_mov_b64 %[m], s[82:83]\n\t"
+        "s_branch PKB_DISPATCH_%=\n\t"
+        // ---------------- defer: push the node on the private stacks of the lanes in m ----------------
+        "PKB_DEFER_%=:\n\t"
+        "s_and_b32 s88, %[cnt], 0xffff\n\t"
+        "s_cmp_ge_u32 s88, 16\n\t"                          // packable entry: leaf count < 16, first < 2^24
+        "s_cbranch_scc1 PKB_NODEFER_%=\n\t"
+        "s_cmp_ge_u32 %[first], 0x1000000\n\t"
+        "s_cbranch_scc1 PKB_NODEFER_%=\n\t"
+        "v_cmp_le_u32 vcc, 8, %[psp]\n\t"                   // every lane of m needs room on its private stack
+        "s_and_b64 s[84:85], vcc, %[m]\n\t"
+        "s_cmp_lg_u64 s[84:85], 0\n\t"
+        "s_cbranch_scc1 PKB_NODEFER_%=\n\t"
+        "s_lshr_b32 s89, %[cnt], 30\n\t"
+        "s_lshl_b32 s89, s89, 28\n\t"
+        "s_lshl_b32 s90, s88, 24\n\t"
+        "s_or_b32 s89, s89, s90\n\t"
+        "s_or_b32 s89, s89, %[first]\n\t"
+        "s_or_b32 s89, s89, 0x40000000\n\t"
+        "s_mov_b64 s[84:85], exec\n\t"
+        "s_mov_b64 exec, %[m]\n\t"
+        "v_lshl_add_u32 %[t0], %[psp], 8, %[llds]\n\t"
+        "v_mov_b32 %[t1], s89\n\t"
+        "ds_write_b32 %[t0], %[t1]\n\t"
+        "v_add_u32 %[psp], 1, %[psp]\n\t"
+        "s_mov_b64 exec, s[84:85]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_branch PKB_POP_%=\n\t"
+        // ---------------- leaf: triangles first .. first + count - 1 ----------------
+        "PKB_LEAF_%=:\n\t"
+        "s_mov_b32 s98, %[first]\n\t"
+        "s_add_i32 s99, %[first], s88\n\t"
+        "PKB_TRI_%=:\n\t"
+        "s_lshl_b32 s89, s98, 6\n\t"
+        "s_load_dwordx8 s[64:71], s[96:97], s89\n\t"
+        "s_add_u32 s89, s89, 32\n\t"
+        "s_load_dwordx4 s[72:75], s[96:97], s89\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        // h = cross(d, e2)                                      p0 = s64..66, e1 = s68..70, e2 = s72..74
+        "v_mul_f32 %[t0], s74, %[dy]\n\t"
+        "v_mul_f32 %[t1], s73, %[dz]\n\t"
+        "v_mul_f32 %[t2], s72, %[dz]\n\t"
+        "v_mul_f32 %[t3], s74, %[dx]\n\t"
+        "v_mul_f32 %[t4], s73, %[dx]\n\t"
+        "v_mul_f32 %[t5], s72, %[dy]\n\t"
+        "v_sub_f32 v84, %[t0], %[t1]\n\t"                    // h.x
+        "v_sub_f32 v85, %[t2], %[t3]\n\t"                    // h.y
+        "v_sub_f32 v86, %[t4], %[t5]\n\t"                    // h.z
+        // a = e1.x*h.x + (e1.y*h.y + e1.z*h.z)
+        "v_mul_f32 %[t0], s69, v85\n\t"
+        "v_mul_f32 %[t1], s70, v86\n\t"
+        "v_mul_f32 %[t2], s68, v84\n\t"
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_add_f32 %[t9], %[t2], %[t0]\n\t"                  // a
+        // f = 1.0f / a, correctly rounded (the expansion hipcc emits for IEEE division with denormals enabled)
+        "v_div_scale_f32 %[t0], s[84:85], %[t9], %[t9], 1.0\n\t"
+        "v_rcp_f32 %[t1], %[t0]\n\t"
+        "v_div_scale_f32 %[t2], vcc, 1.0, %[t9], 1.0\n\t"
+        // s = o - p0 (independent work in the shadow of the rcp)
+        "v_subrev_f32 v87, s64, %[ox]\n\t"
+        "v_fma_f32 %[t3], -%[t0], %[t1], 1.0\n\t"
+        "v_fmac_f32 %[t1], %[t3], %[t1]\n\t"
+        "v_mul_f32 %[t4], %[t2], %[t1]\n\t"
+        "v_fma_f32 %[t5], -%[t0], %[t4], %[t2]\n\t"
+        "v_fmac_f32 %[t4], %[t5], %[t1]\n\t"
+        "v_fma_f32 %[t0], -%[t0], %[t4], %[t2]\n\t"
+        "v_subrev_f32 v88, s65, %[oy]\n\t"
+        "v_div_fmas_f32 %[t0], %[t0], %[t1], %[t4]\n\t"
+        "v_subrev_f32 v89, s66, %[oz]\n\t"
+        "v_div_fixup_f32 %[t8], %[t0], %[t9], 1.0\n\t"       // f
+        // u = f * (s.x*h.x + (s.y*h.y + s.z*h.z))
+        "v_mul_f32 %[t0], v88, v85\n\t"
+        "v_mul_f32 %[t1], v89, v86\n\t"
+        "v_mul_f32 %[t2], v87, v84\n\t"
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_add_f32 %[t0], %[t2], %[t0]\n\t"
+        "v_mul_f32 %[t7], %[t8], %[t0]\n\t"                  // u
+        "v_cmp_lt_f32 s[84:85], 0, %[t7]\n\t"                // u > 0
+        "v_cmp_gt_f32 s[86:87], 1.0, %[t7]\n\t"              // u < 1
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
+        "s_and_b64 s[84:85], s[84:85], %[m]\n\t"
+        "s_cmp_lg_u64 s[84:85], 0\n\t"
+        "s_cbranch_scc0 PKB_NEXT_%=\n\t"                     // no lane of the node passes the u test
+        // q = cross(s, e1)
+        "v_mul_f32 %[t0], s70, v88\n\t"
+        "v_mul_f32 %[t1], s69, v89\n\t"
+        "v_mul_f32 %[t2], s68, v89\n\t"
+        "v_mul_f32 %[t3], s70, v87\n\t"
+        "v_mul_f32 %[t4], s69, v87\n\t"
+        "v_mul_f32 %[t5], s68, v88\n\t"
+        "v_sub_f32 v84, %[t0], %[t1]\n\t"                    // q.x  (h is dead)
+        "v_sub_f32 v85, %[t2], %[t3]\n\t"                    // q.y
+        "v_sub_f32 v86, %[t4], %[t5]\n\t"                    // q.z
+        // v = f * (d.x*q.x + (d.y*q.y + d.z*q.z))
+        "v_mul_f32 %[t0], %[dy], v85\n\t"
+        "v_mul_f32 %[t1], %[dz], v86\n\t"
+        "v_mul_f32 %[t2], %[dx], v84\n\t"
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_add_f32 %[t0], %[t2], %[t0]\n\t"
+        "v_mul_f32 %[t6], %[t8], %[t0]\n\t"                  // v
+        // t = f * (e2.x*q.x + (e2.y*q.y + e2.z*q.z))
+        "v_mul_f32 %[t0], s73, v85\n\t"
+        "v_mul_f32 %[t1], s74, v86\n\t"
+        "v_mul_f32 %[t2], s72, v84\n\t"
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_add_f32 %[t0], %[t2], %[t0]\n\t"
+        "v_mul_f32 %[t5], %[t8], %[t0]\n\t"                  // t
+        "v_add_f32 %[t4], %[t7], %[t6]\n\t"                  // u + v
+        "v_cmp_lt_f32 s[86:87], 0, %[t6]\n\t"                // v > 0
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
+        "v_cmp_gt_f32 s[86:87], 1.0, %[t4]\n\t"              // u + v < 1
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
+        "v_cmp_lt_f32 s[86:87], %[eps], %[t5]\n\t"           // t > EPSILON
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
+        "v_cmp_lt_f32 s[86:87], %[t5], %[tcur]\n\t"          // t < max distance
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
+        // lanes that are hit leave the packet
+        "s_andn2_b64 %[alive], %[alive], s[84:85]\n\t"
+        "s_andn2_b64 %[m], %[m], s[84:85]\n\t"
+        "s_cmp_lg_u64 %[m], 0\n\t"
+        "s_cbranch_scc0 PKB_POP_%=\n\t"
+        "PKB_NEXT_%=:\n\t"
+        "s_add_i32 s98, s98, 1\n\t"
+        "s_cmp_lt_i32 s98, s99\n\t"
+        "s_cbranch_scc1 PKB_TRI_%=\n\t"
+        // ---------------- pop ----------------
+        "PKB_POP_%=:\n\t"
+        "s_mov_b64 %[m], 0\n\t"
+        "s_cmp_eq_u64 %[alive], 0\n\t"
+        "s_cbranch_scc1 PKB_END_%=\n\t"
+        "s_cmp_le_i32 %[sp], %[floor]\n\t"
+        "s_cbranch_scc1 PKB_END_%=\n\t"
+        "s_sub_i32 %[sp], %[sp], 1\n\t"
+        "s_mov_b32 m0, %[sp]\n\t"
+        "v_readlane_b32 s84, %[stmlo], m0\n\t"
+        "v_readlane_b32 s85, %[stmhi], m0\n\t"
+        "v_readlane_b32 %[first], %[sta], m0\n\t"
+        "v_readlane_b32 s88, %[stb], m0\n\t"
+        "s_and_b64 %[m], s[84:85], %[alive]\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 PKB_POP_%=\n\t"
+        "s_bfe_u32 %[depth], s88, 0xe0010\n\t"               // depth = (b >> 16) & 0x3fff
+        "s_and_b32 %[cnt], s88, 0xc000ffff\n\t"
+        "s_branch PKB_DISPATCH_%=\n\t"
+        "PKB_END_%=:\n\t"
+        : [first] "+&s"(W.cur_first), [cnt] "+&s"(W.cur_cnt), [m] "+&s"(W.m), [alive] "+&s"(W.alive), [sp] "+&s"(W.sp), [depth] "+&s"(depth),
+          [maxd] "+&s"(maxd), [err] "+&s"(err), [steps] "+&s"(steps),
+          [sta] "+&v"(W.st_a), [stb] "+&v"(W.st_b), [stmlo] "+&v"(W.st_mlo), [stmhi] "+&v"(W.st_mhi), [psp] "+&v"(W.psp),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7),
+          [t8] "=&v"(t8), [t9] "=&v"(t9)
+        : [nodes] "s"(nodes), [tris] "s"(tris), [floor] "s"(floor_sp),
+          [oxy] "v"(W.ray.o_xy), [ozz] "v"(W.ray.o_zz), [ixy] "v"(W.ray.i_xy), [izz] "v"(W.ray.i_zz), [tcur] "v"(W.ray.tcur),
+          [ox] "v"(W.ray.o_xy.x), [oy] "v"(W.ray.o_xy.y), [oz] "v"(W.ray.o_zz.x), [dx] "v"(W.ray.d.x), [dy] "v"(W.ray.d.y), [dz] "v"(W.ray.d.z),
+          [eps] "s"(eps), [t0d] "s"(defer_t0), [llds] "v"(lane_lds)
+        : "vcc", "scc", "m0", "memory",
+          "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
+          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
+          "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+    W.depth = depth; W.pk_steps = steps;
+    if (maxd + 2 > stack_size || err) W.err = 1;       // reference stack: `depth` pending + 2 pushed at the deepest inner node expanded
+}
+
+struct PkHybrid { int * stk; uint32_t lane_lds; int * spill; int spill_stride; int t0; };
+
+// ---- hybrid any-hit walk, per-lane phase -----------------------------------------------------------------------------------------
+// Walks the subtrees the packet walk handed to the lanes' private stacks (entries are nodes that already passed the lane's slab test,
+// packed like k_trace_fast's: 0x40000000 | axis << 28 | leaf count << 24 | first).  One ray per lane, per-lane gathers through the
+// vector memory path, private stack striped through LDS ([entry][lane], RTX_PK_PRIV entries, deeper ones in HBM): the part of the tree
+// where the rays of a packet no longer agree is walked the way the per-lane kernel walks it, the shared top of the tree was not.
+#define RTX_PK_PRIV 24
+RTX_D void pk_lane_phase_any(PkWalk & W, const int lane, int * const stk, int * const spill, const int spill_stride, rtx_gptr nodes, rtx_gptr tris) {
+    bool live = (W.alive >> lane) & 1ull;
+    int psp = live ? W.psp : 0;
+    const v3 co = V3(W.ray.o_xy.x, W.ray.o_xy.y, W.ray.o_zz.x), cd = W.ray.d, cinv = V3(W.ray.i_xy.x, W.ray.i_xy.y, W.ray.i_zz.x);
+    const float tmax = W.ray.tcur;
+    bool have_cur = false; int cur_first = 0, cur_cnt = 0;
+    auto push = [&](int e) {
+        if (psp < RTX_PK_PRIV) stk[psp * RTX_WAVE] = e;
+        else if (psp < RTX_MAX_STACK + 8) spill[(psp - RTX_PK_PRIV) * spill_stride] = e;
+        else { W.err = 1; return; }
+        psp++;
+    };
+    for (;;) {
+        if (__ballot(live && (have_cur || psp > 0)) == 0ull) break;
+        // inner node: child-pair gather, both slab tests, descend left, push right (any order is exact for any-hit rays)
+        if (live && have_cur && (cur_cnt & 0x3fffffff) == 0) {
+            const int left = cur_first;
+            const float4 la = gld(nodes, 2 * left), lb = gld(nodes, 2 * left + 1), ra = gld(nodes, 2 * left + 2), rb = gld(nodes, 2 * left + 3);
+            float k;
+            const bool pl = slab_test_sel<true>(la, lb, co, cinv, tmax, k), pr = slab_test_sel<true>(ra, rb, co, cinv, tmax, k);
+            if (pl) {
+                if (pr) {
+                    const int rf = as_i(ra.w), rc = as_i(rb.w), rl = rc & 0x3fffffff;
+                    if ((uint32_t)rf < (1u << 24) && rl < 16) push((int)(0x40000000u | (((uint32_t)rc >> 30) << 28) | ((uint32_t)rl << 24) | (uint32_t)rf));
+                    else push(left + 1);
+                }
+                cur_first = as_i(la.w); cur_cnt = as_i(lb.w);
+            } else if (pr) { cur_first = as_i(ra.w); cur_cnt = as_i(rb.w); }
+            else have_cur = false;
+        }
+        // leaf
+        if (live && have_cur && (cur_cnt & 0x3fffffff) > 0) {
+            have_cur = false;
+            const int cnt = cur_cnt & 0x3fffffff;
+            for (int i = cur_first; i < cur_first + cnt; i++) {
+                const float4 p0 = gld(tris, RTX_TRI_STRIDE * i), e1 = gld(tris, RTX_TRI_STRIDE * i + 1), e2 = gld(tris, RTX_TRI_STRIDE * i + 2);
+                const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
+                const v3 h = vcross(cd, edge_2);
+                const float a = vdot(edge_1, h);
+                const float f = 1.0f / a;
+                const v3 s = vsub(co, V3(p0.x, p0.y, p0.z));
+                const float u = f * vdot(s, h);
+                if (!((u > 0.0f) & (u < 1.0f))) continue;
+                const v3 qq = vcross(s, edge_1);
+                const float v = f * vdot(cd, qq);
+                if (!((v > 0.0f) & ((u + v) < 1.0f))) continue;
+                const float t = f * vdot(edge_2, qq);
+                if (!((t > RAY_EPSILON) & (t < tmax))) continue;
+                live = false; break;
+            }
+        }
+        // pop
+        if (live && !have_cur && psp > 0) {
+            psp--;
+            const int e = (psp < RTX_PK_PRIV) ? stk[psp * RTX_WAVE] : spill[(psp - RTX_PK_PRIV) * spill_stride];
+            if (e & 0x40000000) { cur_first = e & 0x00ffffff; cur_cnt = (int)((((uint32_t)e >> 28) & 3u) << 30) | ((e >> 24) & 15); }
+            else { const float4 na = gld(nodes, 2 * e), nb = gld(nodes, 2 * e + 1); cur_first = as_i(na.w); cur_cnt = as_i(nb.w); }
+            have_cur = true;
+        }
+    }
+    W.alive &= __ballot(live);            // lanes that found an occluder leave the packet
+    W.psp = 0;
+}
+
+// Walks until the packet is finished (returns true) or, FAST only, until an instance is entered in which some lane's inverse
+// direction is not finite (returns false: the caller continues with the reference-form variant; the state is consistent).
+// `world(o, d)` reloads a lane's world-space ray (kept in memory, not in registers).
+template <bool ANY, bool PSTAT, bool FAST, bool ASM, typename WorldFn>
+RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool ordered, const PkHybrid & H, WorldFn && world) {
+    for (;;) {
+        if (W.m != 0ull) {
+            const int leafc = W.cur_cnt & 0x3fffffff;
+            if (leafc > 0) {
+                PK_T0();
+                if (W.floor_sp >= 0) {
+                    // BLAS leaf: triangle_trace / triangle_intersect (BottomLevelBVH.cpp:214-346) with the triangle in SGPRs
+                    const v3 co = V3(W.ray.o_xy.x, W.ray.o_xy.y, W.ray.o_zz.x), cd = W.ray.d;
+                    for (int i = W.cur_first; i < W.cur_first + leafc; i++) {
+                        const float4 p0 = sld(W.tris, RTX_TRI_STRIDE * i), e1 = sld(W.tris, RTX_TRI_STRIDE * i + 1), e2 = sld(W.tris, RTX_TRI_STRIDE * i + 2);
+                        if (PSTAT) { W.st_tris++; W.st_tri_lanes += (unsigned long long)__popcll(W.m); }
+                        const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
+                        const v3 h = vcross(cd, edge_2);
+                        const float a = vdot(edge_1, h);
+                        const float f = 1.0f / a;
+                        const v3 s = vsub(co, V3(p0.x, p0.y, p0.z));
+                        const float u = f * vdot(s, h);
+                        const v3 qq = vcross(s, edge_1);
+                        const float v = f * vdot(cd, qq);
+                        const float t = f * vdot(edge_2, qq);
+                        const bool hit = (u > 0.0f) & (u < 1.0f) & (v > 0.0f) & ((u + v) < 1.0f) & (t > RAY_EPSILON) & (t < W.ray.tcur);
+                        const unsigned long long hm = __ballot(hit) & W.m;
+                        if (hm != 0ull) {
+                            const bool mine = (hm >> lane) & 1ull;
+                            if (ANY) { if (mine) W.occluded = true; W.alive &= ~hm; W.m &= ~hm; if (W.m == 0ull) break; }
+                            else if (mine) { W.ray.tcur = t; W.best_u = u; W.best_v = v; W.best_tri = i; W.best_prim = PRIM_TRI | W.cur_inst; }
+                        }
+                    }
+                } else {
+                    // TLAS leaf: the reference enters the instances first .. first+count-1 in order (TopLevelBVH.cpp:71-75);
+                    // one iterator entry instead of `count` entries keeps the packet stack bounded
+                    pk_push<ANY>(W, W.cur_first, leafc, W.m, 0, PK_FLAG_ITER);
+                }
+                W.m = 0ull;
+                PK_T1(2);
+            } else if (ASM && FAST) {
+                PK_T0();
+                pk_descend<ANY>(W, sc.stack_size, ordered ? 1 : 0);      // inner nodes, hand-scheduled: down to a leaf (or m == 0)
+                PK_T1(1);
+            } else {
+                // inner node.  Reference stack: `depth` pending entries, two pushed before one is popped (BottomLevelBVH.cpp:381-387)
+                if (W.depth + 2 > sc.stack_size) W.err = 1;
+                int left_first = 1;                                      // BVHNode::should_visit_left_first, BVHNode.h:30-40 (wave-uniform int: scalar selects)
+                if (ordered) {
+                    const int axis = (int)((uint32_t)W.cur_cnt >> 30);
+                    if (axis != 0) {
+                        const float c = axis == 1 ? W.ray.d.x : (axis == 2 ? W.ray.d.y : W.ray.d.z);
+                        const unsigned long long pos = __ballot(c > 0.0f) & W.m;
+                        if (ANY) left_first = (int)((pos >> (__ffsll((long long)W.m) - 1)) & 1ull);      // any order is exact: the first lane's
+                        else if (pos == 0ull) left_first = 0;
+                        else if (pos != W.m) {
+                            // lanes disagree on the order: park the right-first lanes on this node, walk the left-first lanes now
+                            pk_push<ANY>(W, W.cur_first, W.cur_cnt, W.m & ~pos, W.cur_idx, W.depth | PK_FLAG_PRETESTED);
+                            W.m = pos;
+                        }
+                    }
+                }
+                left_first = rfl(left_first);
+                const int left = W.cur_first;
+                const float4 la = sld(W.nodes, 2 * left), lb = sld(W.nodes, 2 * left + 1), ra = sld(W.nodes, 2 * left + 2), rb = sld(W.nodes, 2 * left + 3);
+                if (PSTAT) { W.st_pairs++; W.st_pair_lanes += (unsigned long long)__popcll(W.m); }
+                const unsigned long long ml = __ballot(pk_slab<FAST>(la, lb, W.ray)) & W.m, mr = __ballot(pk_slab<FAST>(ra, rb, W.ray)) & W.m;
+                const unsigned long long m_near = left_first ? ml : mr, m_far = left_first ? mr : ml;
+                const int near_idx = left_first ? left : left + 1, far_idx = left_first ? left + 1 : left;
+                const int near_first = left_first ? as_i(lb.z) : as_i(rb.z), near_cnt = left_first ? as_i(lb.w) : as_i(rb.w);
+                const int far_first  = left_first ? as_i(rb.z) : as_i(lb.z), far_cnt  = left_first ? as_i(rb.w) : as_i(lb.w);
+                if (m_near != 0ull) {
+                    if (m_far != 0ull) pk_push<ANY>(W, far_first, far_cnt, m_far, far_idx, W.depth);       // popped with `depth` entries pending
+                    W.cur_idx = rfl(near_idx); W.cur_first = rfl(near_first); W.cur_cnt = rfl(near_cnt); W.m = m_near; W.depth = rfl(W.depth + 1);   // far sibling pending below us
+                } else if (m_far != 0ull) {
+                    W.cur_idx = rfl(far_idx); W.cur_first = rfl(far_first); W.cur_cnt = rfl(far_cnt); W.m = m_far;   // near popped and failed, far popped: depth unchanged
+                } else W.m = 0ull;
+            }
+            continue;
+        }
+        // ---------------- pop ----------------
+        PK_T0();
+        if (ANY && W.alive == 0ull) return true;
+        if (W.floor_sp >= 0 && W.sp == W.floor_sp) {            // BottomLevelBVH::trace / intersect returned: back to world space
+            W.floor_sp = -1; W.nodes = W.tlas;
+            v3 o, d; world(o, d);
+            pk_set_ray(W.ray, o, d, vrcp(d));                   // finite for every lane of a packet that started FAST
+        }
+        if (W.sp == 0) return true;
+        W.sp--;
+        const int ea = __builtin_amdgcn_readlane(W.st_a, W.sp), eb = __builtin_amdgcn_readlane(W.st_b, W.sp);
+        const int edf = __builtin_amdgcn_readlane(W.st_df, W.sp);
+        const unsigned long long em = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(W.st_mhi, W.sp) << 32) |
+                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(W.st_mlo, W.sp);
+        const unsigned long long pm = em & W.alive;
+        if (pm == 0ull) continue;
+        if (edf & PK_FLAG_ITER) {
+            if (eb > 1) pk_push<ANY>(W, ea + 1, eb - 1, pm, 0, PK_FLAG_ITER);
+            // Mesh::trace / Mesh::intersect (Mesh.cpp:17-40): ray into model space
+            const int inst = rfl(sc.tlas_indices[ea]);
+            const rtx_instance & I = sc.instances[inst];
+            v3 o, d; world(o, d);
+            const v3 co = xform_pos(I.world_inv, o), cd = xform_dir(I.world_inv, d), cinv = vrcp(cd);
+            pk_set_ray(W.ray, co, cd, cinv);
+            const DevBlas & B = sc.blas[rfl(I.blas_id)];
+            W.nodes = pk_cptr(B.pk_nodes); W.tris = pk_cptr(B.tri_hot); W.cur_inst = inst;
+            W.floor_sp = W.sp; W.depth = 0;
+            const float4 na = sld(W.nodes, 0), nb = sld(W.nodes, 1);            // BLAS root (BottomLevelBVH.cpp:360-370)
+            const bool risky = FAST && __ballot(W.valid && !inv_is_finite(cinv)) != 0ull;
+            W.m = (risky ? __ballot(pk_slab<false>(na, nb, W.ray)) : __ballot(pk_slab<FAST>(na, nb, W.ray))) & pm;
+            W.cur_idx = 0; W.cur_first = as_i(nb.z); W.cur_cnt = as_i(nb.w);
+            if (risky) return false;
+            if (ASM && FAST && ANY) {
+                // the whole BLAS walk, hand-scheduled (returns with m == 0), then the per-lane phase over what it deferred
+                PK_T0();
+                W.psp = 0;
+                pk_blas_any_asm(W, sc.stack_size, H.lane_lds, H.t0);
+                PK_T1(1);
+                if (W.alive != 0ull && __ballot(W.psp > 0) != 0ull) { PK_T0(); pk_lane_phase_any(W, lane, H.stk, H.spill, H.spill_stride, RTX_GPTR(B.nodes), RTX_GPTR(B.tri_hot)); PK_T1(2); }
+            }
+        } else {
+            W.m = pm;
+            if (!ANY && !(edf & PK_FLAG_PRETESTED)) {
+                // far child: the reference tests it now, against each lane's current closest distance
+                const int eidx = __builtin_amdgcn_readlane(W.st_idx, W.sp);
+                const float4 na = sld(W.nodes, 2 * eidx), nb = sld(W.nodes, 2 * eidx + 1);
+                W.m = __ballot(pk_slab<FAST>(na, nb, W.ray)) & pm;
+                W.cur_idx = eidx;
+            } else if (!ANY) W.cur_idx = __builtin_amdgcn_readlane(W.st_idx, W.sp);
+            W.cur_first = rfl(ea); W.cur_cnt = rfl(eb); W.depth = rfl(edf & 0xffff);
+        }
+        PK_T1(3);
+    }
+}
+
+template <bool ANY, bool PSTAT>
+__global__ __launch_bounds__(RTX_PK_BLOCK, ANY ? RTX_PK_WAVES_ANY : RTX_PK_WAVES_CLOSEST)
+void k_packet(const DevScene sc, const DevQueues q, const int level, const int level_hi) {
+    // hybrid any-hit walk: the lanes' private stacks, striped through LDS ([entry][lane]: conflict-free)
+    __shared__ int s_priv[ANY ? RTX_PK_BLOCK / RTX_WAVE : 1][ANY ? RTX_PK_PRIV : 1][RTX_WAVE];
+    const int lane = threadIdx.x & 63;
+    PkHybrid H;
+    H.stk = &s_priv[ANY ? (threadIdx.x >> 6) : 0][0][lane];
+    H.lane_lds = (uint32_t)(uintptr_t)H.stk;
+    H.spill_stride = q.spill_threads;
+    H.spill = q.spill + 2 * (size_t)q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) + (blockIdx.x * blockDim.x + threadIdx.x);
+    H.t0 = q.pk_defer_t0;
+    const uint32_t gwave  = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
+    const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE);
+
+    DevCounters * const ctr = q.counters;
+    const int nL = sc.light_count;
+    // packets: closest-hit = consecutive 64-slot groups of the level's queue; any-hit = per (level, light) segment, each padded
+    // to whole packets so that a packet never mixes lights or levels
+    uint32_t npk = 0;
+    if (ANY) { for (int d = level; d <= level_hi; d++) npk += ((ctr->lit_count[d] + 63u) >> 6) * (uint32_t)nL; }
+    else npk = (ctr->ray_count[level] + 63u) >> 6;
+    npk = (uint32_t)rfl((int)npk);
+    uint32_t * const heads = q.pk_heads + (size_t)((ANY ? RTX_MAX_LEVELS + 1 : 0) + level) * RTX_PK_CLASSES * 32;
+    const bool ordered = sc.traversal_strategy == RTX_TRAVERSE_ORDERED;
+
+    PkWalk W;
+#ifdef RTX_PK_PROF
+    for (int i = 0; i < 10; i++) W.prof[i] = 0ull;
+    const unsigned long long pk_k0_ = __builtin_amdgcn_s_memtime();
+#endif
+    W.tlas = pk_cptr(sc.pk_tlas_nodes);
+    W.err = 0; W.st_pairs = W.st_tris = W.st_pair_lanes = W.st_tri_lanes = 0ull;
+    W.st_a = W.st_b = W.st_mlo = W.st_mhi = W.st_idx = W.st_df = 0;
+    unsigned long long st_packets = 0ull;
+
+    uint32_t cls = gwave & (RTX_PK_CLASSES - 1);
+    int probes_left = 2;                       // own head, then one neighbour (steal), then stop
+    bool first_round = true;
+    const bool all_static = nwaves >= npk;     // every packet is covered by the static first round: no atomics at all
+
+    for (;;) {
+        // ---------------- next packet ----------------
+        PK_T0();
+        uint32_t pk;
+        if (first_round) { first_round = false; pk = gwave; if (pk >= npk) break; }      // static first round: wave w takes packet w
+        else {
+            if (all_static) break;
+            bool got = false;
+            while (probes_left > 0) {
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(&heads[cls * 32], 1u);
+                k = (uint32_t)rfl((int)k);
+                pk = k * RTX_PK_CLASSES + cls;
+                if (pk < npk) { got = true; break; }
+                cls = (cls + 1) & (RTX_PK_CLASSES - 1); probes_left--;
+            }
+            if (!got) break;
+        }
+
+        // ---------------- the packet's rays ----------------
+        W.valid = false; W.occluded = false;
+        uint32_t out_slot = 0;
+        v3 wo = V3(0.0f, 0.0f, 0.0f), wd = V3(1.0f, 1.0f, 1.0f);
+        W.ray.tcur = INFINITY;
+        W.best_prim = PRIM_NONE; W.best_tri = 0; W.best_u = 0.0f; W.best_v = 0.0f;
+        bool clipped = false;
+        uint32_t pix_idx = 0;
+        if (ANY) {
+            uint32_t local = pk; int d = level;
+            uint32_t lit_n = ctr->lit_count[d], seg = (lit_n + 63u) >> 6;
+            while (d < level_hi && local >= seg * (uint32_t)nL) { local -= seg * (uint32_t)nL; d++; lit_n = ctr->lit_count[d]; seg = (lit_n + 63u) >> 6; }
+            const uint32_t light = local / seg, rank = (local - light * seg) * 64u + (uint32_t)lane;
+            W.valid = rank < lit_n;
+            if (W.valid) {
+                out_slot = (uint32_t)q.shadow_base[d] + light * (uint32_t)q.level_cap[d] + rank;
+                const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot];
+                wo = V3(s0.x, s0.y, s0.z); W.ray.tcur = s0.w; wd = V3(s1.x, s1.y, s1.z);
+                if (W.ray.tcur < 0.0f) W.valid = false;          // culled by k_shade<.., CULL>: contribution exactly zero, already resolved
+            }
+        } else {
+            pix_idx = pk * 64u + (uint32_t)lane;
+            W.valid = pix_idx < ctr->ray_count[level];
+            if (W.valid) {
+                out_slot = (uint32_t)q.level_base[level] + pix_idx;
+                if (level == 0) {
+                    int px, py;
+                    if (primary_pixel(sc, q, pix_idx, px, py)) { RayFull r; primary_ray(sc, px, py, r, false); wo = r.o; wd = r.d; }
+                    else { clipped = true; W.valid = false; }
+                } else {
+                    const float4 r0 = q.r0[out_slot], r1 = q.r1[out_slot];
+                    wo = V3(r0.x, r0.y, r0.z); wd = V3(r0.w, r1.x, r1.y);
+                }
+            }
+        }
+        // the world-space ray is not kept in registers while an instance is walked: it is reloaded (or regenerated) when the walk
+        // returns to the TLAS and when the next instance is entered
+        auto world = [&](v3 & o, v3 & d) {
+            o = V3(0.0f, 0.0f, 0.0f); d = V3(1.0f, 1.0f, 1.0f);
+            if (!W.valid) return;
+            if (ANY) { const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot]; o = V3(s0.x, s0.y, s0.z); d = V3(s1.x, s1.y, s1.z); }
+            else if (level == 0) { int px, py; primary_pixel(sc, q, pix_idx, px, py); RayFull r; primary_ray(sc, px, py, r, false); o = r.o; d = r.d; }
+            else { const float4 r0 = q.r0[out_slot], r1 = q.r1[out_slot]; o = V3(r0.x, r0.y, r0.z); d = V3(r0.w, r1.x, r1.y); }
+        };
+        // Scene::trace_primitives / intersect_primitives: spheres, then planes, then the TLAS (Scene.cpp:173-190)
+        if (W.valid) {
+            for (int i = 0; i < sc.sphere_count; i++) {
+                if (ANY) { if (sphere_any(sc.spheres[i], wo, wd, W.ray.tcur)) { W.occluded = true; break; } }
+                else { float t; if (sphere_closest(sc.spheres[i], wo, wd, W.ray.tcur, t)) { W.ray.tcur = t; W.best_prim = PRIM_SPHERE | i; } }
+            }
+            if (!W.occluded) for (int i = 0; i < sc.plane_count; i++) {
+                const float t = plane_t(sc.planes[i], wo, wd);
+                if ((t > RAY_EPSILON) & (t < W.ray.tcur)) { if (ANY) { W.occluded = true; break; } else { W.ray.tcur = t; W.best_prim = PRIM_PLANE | i; } }
+            }
+        }
+        W.psp = 0; W.pk_steps = 0;
+        W.alive = __ballot(W.valid && !W.occluded);     // any-hit: lanes leave when occluded; closest-hit: constant
+        const unsigned long long alive0 = W.alive;
+        if (PSTAT) st_packets++;
+
+        if (W.alive != 0ull && sc.tlas_node_count > 0) {
+            const v3 winv = vrcp(wd);
+            pk_set_ray(W.ray, wo, wd, winv);
+            const bool nanfree_world = __ballot(W.valid && !inv_is_finite(winv)) == 0ull;
+            W.nodes = W.tlas; W.tris = W.tlas;
+            W.sp = 0; W.floor_sp = -1; W.cur_inst = 0; W.depth = 0; W.cur_idx = 0;
+            {   // TLAS root: pushed, popped and tested by the reference (TopLevelBVH.cpp:58-67)
+                const float4 na = sld(W.nodes, 0), nb = sld(W.nodes, 1);
+                W.m = __ballot(pk_slab<false>(na, nb, W.ray)) & W.alive;
+                W.cur_first = as_i(nb.z); W.cur_cnt = as_i(nb.w);
+            }
+            PK_T1(0);
+#ifdef RTX_PK_PROF
+            const unsigned long long pk_w0_ = __builtin_amdgcn_s_memtime();
+#endif
+            bool done = false;
+            if (nanfree_world) done = pk_walk<ANY, PSTAT, true, !PSTAT>(sc, W, lane, ordered, H, world);
+            if (!done) pk_walk<ANY, PSTAT, false, false>(sc, W, lane, ordered, H, world);
+#ifdef RTX_PK_PROF
+            {   // slot 4: the longest single packet walk (max), slot 9: walks longer than 2^18 ticks
+                const unsigned long long dt = __builtin_amdgcn_s_memtime() - pk_w0_;
+                if (dt > W.prof[4]) W.prof[4] = dt;
+                if (dt > (1ull << 18)) W.prof[9]++;
+            }
+#endif
+        }
+
+        // ---------------- results ----------------
+        if (ANY) { if (((alive0 & ~W.alive) >> lane) & 1ull) W.occluded = true; }      // lanes that left the packet were hit
+        if (ANY) { if (W.valid) q.socc[out_slot] = W.occluded ? 1u : 0u; }
+        else if (W.valid) { q.h0[out_slot] = make_float4(W.ray.tcur, W.best_u, W.best_v, as_f(W.best_prim)); q.h1[out_slot] = W.best_tri; }
+        else if (clipped) { q.h0[out_slot] = make_float4(INFINITY, 0.0f, 0.0f, as_f(PRIM_NONE)); q.h1[out_slot] = -1; }   // clipped pixel: never shaded
+    }
+
+#ifdef RTX_PK_PROF
+    W.prof[6] = __builtin_amdgcn_s_memtime() - pk_k0_;          // this wave's lifetime
+    W.prof[7] = __builtin_amdgcn_s_memtime();                    // last end (max)
+    W.prof[8] = (1ull << 62) - pk_k0_;                           // first start (max of the complement)
+    if (lane == 0) for (int i = 0; i < 10; i++) { if (i == 4 || i == 7 || i == 8) atomicMax(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); else atomicAdd(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); }
+#endif
+    if (W.err) { if (lane == 0) atomicOr(&ctr->error_flags, ERR_STACK_OVERFLOW); }
+    if (PSTAT && lane == 0) {
+        atomicAdd(&ctr->work[15 + PKS_PACKETS], st_packets); atomicAdd(&ctr->work[15 + PKS_PAIR_STEPS], W.st_pairs);
+        atomicAdd(&ctr->work[15 + PKS_TRI_STEPS], W.st_tris); atomicAdd(&ctr->work[15 + PKS_PAIR_LANES], W.st_pair_lanes);
+        atomicAdd(&ctr->work[15 + PKS_TRI_LANES], W.st_tri_lanes);
+    }
+}

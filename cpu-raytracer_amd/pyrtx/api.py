@@ -26,6 +26,9 @@ RTX_RENDER_COUNT_WORK = 1
 RTX_RENDER_SIMPLE_TRACE = 2
 RTX_RENDER_CULL_DEAD_SHADOW_RAYS = 4
 RTX_RENDER_SERIAL = 8
+RTX_RENDER_LANE_TRACE = 16
+RTX_RENDER_PACKET_STATS = 32
+RTX_RENDER_PACKET_CLOSEST = 64
 ERRORS = {1: "RTX_ERR_INVALID_ARG", 2: "RTX_ERR_NO_DEVICE", 3: "RTX_ERR_HIP", 4: "RTX_ERR_LIMIT", 5: "RTX_ERR_STATE", 6: "RTX_ERR_OOM"}
 
 _lib = None
@@ -133,11 +136,14 @@ class Renderer:
         self._chk(self.lib.rtx_set_frame(self.ctx, C.byref(fr)), "rtx_set_frame")
 
     def render_async(self, first_tile: int = 0, tile_stride: int = 1, tile_count: Optional[int] = None, count_work: bool = False,
-                     simple_trace: bool = False, cull_dead_shadow_rays: bool = False, serial: bool = False):
+                     simple_trace: bool = False, cull_dead_shadow_rays: bool = False, serial: bool = False, lane_trace: bool = False,
+                     packet_stats: bool = False, packet_closest: bool = False):
         if tile_count is None:
             tile_count = (self.scene.tile_count - first_tile + tile_stride - 1) // tile_stride
         flags = ((RTX_RENDER_COUNT_WORK if count_work else 0) | (RTX_RENDER_SIMPLE_TRACE if simple_trace else 0)
-                 | (RTX_RENDER_CULL_DEAD_SHADOW_RAYS if cull_dead_shadow_rays else 0) | (RTX_RENDER_SERIAL if serial else 0))
+                 | (RTX_RENDER_CULL_DEAD_SHADOW_RAYS if cull_dead_shadow_rays else 0) | (RTX_RENDER_SERIAL if serial else 0)
+                 | (RTX_RENDER_LANE_TRACE if lane_trace else 0) | (RTX_RENDER_PACKET_STATS if packet_stats else 0)
+                 | (RTX_RENDER_PACKET_CLOSEST if packet_closest else 0))
         self._chk(self.lib.rtx_render_tiles(self.ctx, first_tile, tile_stride, tile_count, flags), "rtx_render_tiles")
 
     def synchronize(self):
@@ -167,8 +173,9 @@ class Renderer:
         return a.value, b.value
 
     def render(self, first_tile: int = 0, tile_stride: int = 1, tile_count: Optional[int] = None, count_work: bool = False,
-               simple_trace: bool = False, cull_dead_shadow_rays: bool = False, serial: bool = False) -> Dict:
-        self.render_async(first_tile, tile_stride, tile_count, count_work, simple_trace, cull_dead_shadow_rays, serial)
+               simple_trace: bool = False, cull_dead_shadow_rays: bool = False, serial: bool = False, lane_trace: bool = False,
+               packet_stats: bool = False, packet_closest: bool = False) -> Dict:
+        self.render_async(first_tile, tile_stride, tile_count, count_work, simple_trace, cull_dead_shadow_rays, serial, lane_trace, packet_stats, packet_closest)
         stats, work = self.stats()
         rgb, packed = self.framebuffer()
         return {"rgb": rgb, "packed": packed, "stats": stats, "work": work}

@@ -56,7 +56,11 @@ class RtxWork(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in _WORK_FIELDS] + [("reserved", C.c_uint64 * 5)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n in _WORK_FIELDS}
+        d = {n: int(getattr(self, n)) for n in _WORK_FIELDS}
+        # RTX_RENDER_PACKET_STATS (csrc/rtx_packet.h): packet-walk figures, closest-hit and shadow-ray launches summed
+        for i, n in enumerate(("pk_packets", "pk_pair_steps", "pk_tri_steps", "pk_pair_lanes", "pk_tri_lanes")):
+            d[n] = int(self.reserved[i])
+        return d
 
 
 assert C.sizeof(RtxConfig) == 64 and C.sizeof(RtxTextureDesc) == 80 and C.sizeof(RtxCamera) == 48

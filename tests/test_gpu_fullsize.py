@@ -15,13 +15,15 @@ def api():
     return a
 
 
-def test_cfg3_atrium_1080p_whole_frame_vs_oracle(api):
-    """BASELINE configs[2] stand-in at full size: 255 296 triangles, 3 lights, depth 3, 2 073 600 pixels, 10.3 M rays."""
+@pytest.mark.parametrize("serial", [False, True])
+def test_cfg3_atrium_1080p_whole_frame_vs_oracle(api, serial):
+    """BASELINE configs[2] stand-in at full size: 255 296 triangles, 3 lights, depth 3, 2 073 600 pixels, 10.3 M rays; serial = the
+    one-stream launch shape bench.py times (all levels' shadow rays in ONE hybrid-packet launch)."""
     import orc
     from pyrtx import host
     sc = host.atrium_scene(1920, 1080, 3, detail=1)
     r = api.Renderer(sc)
-    out = r.render()
+    out = r.render(serial=serial)
     ref = orc.OracleScene(sc).render(threads=64)
     assert out["stats"] == ref["stats"] == {"primary": 2073600, "shadow": 7657752, "reflection": 587842, "refraction": 20050}
     d = np.abs(out["rgb"].astype(np.float64) - ref["rgb"].astype(np.float64))
@@ -29,13 +31,13 @@ def test_cfg3_atrium_1080p_whole_frame_vs_oracle(api):
     assert util.bit_exact(out["rgb"], ref["rgb"])                # all 2 073 600 pixels, 10.3 M rays: identical
     assert np.array_equal(out["packed"], ref["packed"])
     # idempotence + shard properties on the same context
-    again = r.render()
+    again = r.render(serial=not serial, packet_closest=True)
     assert np.array_equal(again["rgb"].view(np.uint32), out["rgb"].view(np.uint32))
     r2 = api.Renderer(sc)
     total = {k: 0 for k in out["stats"]}
     for g in range(8):                                           # the 8-GPU tile partition, rendered shard by shard on one GPU
         n = (sc.tile_count - g + 7) // 8
-        r2.render_async(g, 8, n)
+        r2.render_async(g, 8, n, serial=serial)
         st, _ = r2.stats()
         for k in total:
             total[k] += st[k]
@@ -44,7 +46,8 @@ def test_cfg3_atrium_1080p_whole_frame_vs_oracle(api):
     assert np.array_equal(rgb.view(np.uint32), out["rgb"].view(np.uint32)) and np.array_equal(packed, out["packed"])
 
 
-def test_cfg5_tori16_1080p_dynamic_frames_vs_oracle(api):
+@pytest.mark.parametrize("serial", [False, True])
+def test_cfg5_tori16_1080p_dynamic_frames_vs_oracle(api, serial):
     """BASELINE configs[4]: 16 instanced tori + dielectric spheres + EWA-textured plane at 1920x1080, TLAS rebuilt and
     re-uploaded every frame (host library), three consecutive frames against the oracle."""
     import orc
@@ -60,7 +63,7 @@ def test_cfg5_tori16_1080p_dynamic_frames_vs_oracle(api):
         _, _, inst, nodes, idx = frame_state("tori16", f)
         sc.instances, sc.tlas_nodes, sc.tlas_indices = inst, nodes, idx
         r.set_frame(sc)
-        out = r.render()
+        out = r.render(serial=serial)
         ref = orc.OracleScene(sc).render(threads=64)
         assert out["stats"] == ref["stats"] and out["stats"]["refraction"] > 0
         d = np.abs(out["rgb"].astype(np.float64) - ref["rgb"].astype(np.float64))

@@ -77,3 +77,8 @@ def test_random_scene_gpu_equals_oracle(seed):
     assert np.array_equal(out["packed"], ref["packed"]), text
     simple = api.Renderer(sc).render(simple_trace=True)                   # plain reference-order kernel == production kernel
     assert np.array_equal(simple["rgb"].view(np.uint32), out["rgb"].view(np.uint32)), text
+    # every other launch shape / kernel choice: the one-stream shape bench.py times (merged shadow-ray launch), per-lane shadow
+    # rays, packet closest-hit rays
+    for kw in ({"serial": True}, {"serial": True, "lane_trace": True}, {"packet_closest": True}, {"serial": True, "packet_closest": True}):
+        alt = r.render(**kw)
+        assert np.array_equal(alt["rgb"].view(np.uint32), out["rgb"].view(np.uint32)) and alt["stats"] == out["stats"], (kw, text)

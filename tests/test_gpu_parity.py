@@ -23,10 +23,24 @@ def api():
     return a
 
 
+# every launch shape / kernel selection rtx_render_tiles knows (include/rtx.h): the default two-stream shape, the one-stream shape
+# bench.py times (RTX_RENDER_SERIAL: ONE merged shadow-ray launch for all levels), and the A/B kernel choices
+MODES = {
+    "default": {},
+    "serial": {"serial": True},
+    "lane": {"lane_trace": True},
+    "serial_lane": {"serial": True, "lane_trace": True},
+    "serial_packet_closest": {"serial": True, "packet_closest": True},
+    "packet_closest": {"packet_closest": True},
+    "serial_cull": {"serial": True, "cull_dead_shadow_rays": True},
+}
+
+
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("name", list(util.GOLDENS))
-def test_frame_matches_reference_golden(api, name):
+def test_frame_matches_reference_golden(api, name, mode):
     sc, g = util.load_golden(name)
-    out = api.Renderer(sc).render()
+    out = api.Renderer(sc).render(**MODES[mode])
     cmp = util.compare_to_golden(out, g)
     assert cmp["stats_equal"], (out["stats"], g["stats"])
     assert cmp["nan_mismatch"] == 0
@@ -124,12 +138,13 @@ def test_pair_fetch_kernels_equal_plain_traversal(api, name):
     assert a["stats"] == b["stats"]
 
 
-def test_atrium_cfg3_small_matches_oracle(api):
+@pytest.mark.parametrize("mode", ["default", "serial", "serial_packet_closest"])
+def test_atrium_cfg3_small_matches_oracle(api, mode):
     """The cfg3 workload (own BVH builder, 64k-triangle detail level) at reduced resolution vs the oracle."""
     import orc
     from pyrtx import host
     sc = host.atrium_scene(480, 270, 3, detail=0)
-    out = api.Renderer(sc).render()
+    out = api.Renderer(sc).render(**MODES[mode])
     ref = orc.OracleScene(sc).render(threads=8)
     assert out["stats"] == ref["stats"]
     d = np.abs(out["rgb"].astype(np.float64) - ref["rgb"].astype(np.float64))
@@ -177,3 +192,40 @@ def test_heatmap_mode_is_bit_exact(api, name):
     r2.render(first_tile=0, tile_stride=2, tile_count=(T + 1) // 2)
     half = r2.render(first_tile=1, tile_stride=2, tile_count=T // 2)
     assert np.array_equal(half["packed"], out["packed"])
+
+
+def test_three_contexts_in_flight_serial_mode(api):
+    """What bench.py times: three contexts, each on its own stream, rendering DIFFERENT frames concurrently with RTX_RENDER_SERIAL
+    (cfg5 frames 1-3: per-frame TLAS), every frame compared with the oracle after all three were queued without a host sync."""
+    import orc
+    from test_dynamic_frames import frame_state
+    scenes, renderers = [], []
+    for f in (1, 2, 3):
+        sc, g, inst, nodes, idx = frame_state("tori16", f)
+        sc.instances, sc.tlas_nodes, sc.tlas_indices = inst, nodes, idx
+        scenes.append(sc); renderers.append(api.Renderer(sc))
+    for rounds in range(3):                                     # keep the three streams busy for a while
+        for r in renderers:
+            r.render_async(serial=True)
+    outs = []
+    for r in renderers:
+        st, _ = r.stats(); rgb, packed = r.framebuffer()
+        outs.append({"rgb": rgb, "packed": packed, "stats": st})
+    for sc, out in zip(scenes, outs):
+        ref = orc.OracleScene(sc).render(threads=8)
+        assert out["stats"] == ref["stats"]
+        assert util.bit_exact(out["rgb"], ref["rgb"]) and np.array_equal(out["packed"], ref["packed"])
+
+
+def test_stack_size_knob_is_honoured(api):
+    """BVH_TRAVERSAL_STACK_SIZE (Config.h:25): the reference's per-BVH stack holds one pending sibling per ancestor entered through its
+    near child and two more while a node is expanded; a configured size the scene's deepest expansion does not fit in must be reported
+    (RTX_ERR_LIMIT from rtx_get_stats), a sufficient one must not."""
+    sc, _ = util.load_golden("monkey_small")
+    sc.config["stack_size"] = 64
+    api.Renderer(sc).render()                                    # fits
+    sc.config["stack_size"] = 3
+    for mode in ("default", "packet_closest", "lane"):
+        with pytest.raises(api.RtxError) as e:
+            api.Renderer(sc).render(**MODES[mode])
+        assert e.value.code == 4, mode

@@ -94,7 +94,8 @@ def test_nan_from_beer_law_is_reproduced(api):
 
 
 def test_stack_overflow_is_reported_not_silent(api):
-    """A degenerate chain-shaped BVH deeper than RTX_MAX_STACK makes the reference smash its stack; here it is an error."""
+    """A degenerate chain-shaped BVH deeper than BVH_TRAVERSAL_STACK_SIZE makes the reference smash its (unchecked) stack; here the tree is
+    refused before anything is launched (RTX_ERR_LIMIT from rtx_render_tiles: an inner node at depth 79 needs 81 entries)."""
     from pyrtx import scene_io as sio
     sc, _ = util.load_golden("cube")
     depth = 80
@@ -111,10 +112,9 @@ def test_stack_overflow_is_reported_not_silent(api):
     sc.blas[0] = sio.Blas(nodes, hot, cold, sc.blas[0].material_offset, 1)
     sc.config["traversal_strategy"] = 0          # naive: always left first
     r = api.Renderer(sc)
-    r.render_async()
     with pytest.raises(api.RtxError) as e:
-        r.stats()
-    assert e.value.code == 4
+        r.render_async()
+    assert e.value.code == 4 and "stack" in str(e.value)
 
 
 def test_dangling_material_and_texture_ids_are_refused_before_launch(api):
