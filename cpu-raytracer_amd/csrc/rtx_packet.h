@@ -382,11 +382,11 @@ RTX_D void pk_descend(PkWalk & W, int stack_size, int ordered) {
 //   Instruction budget per inner step: 34 VALU (+4 v_writelane on a push), 16-24 SALU.
 //   Hazards (gfx940/950): v_rcp_f32 (trans) result is used two instructions later; v_div_scale writes VCC four instructions before
 //   v_div_fmas reads it; SGPRs written by v_cmp are read by SALU only; v_readlane results are consumed by SALU / SMEM (interlocked).
-RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, int defer_t0) {
+RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, int defer_t0, int grow_shift) {
     W.cur_first = rfl(W.cur_first); W.cur_cnt = rfl(W.cur_cnt); W.m = rfl64(W.m); W.alive = rfl64(W.alive); W.sp = rfl(W.sp);
     int depth = rfl(W.depth), maxd = -1, err = 0, steps = rfl(W.pk_steps);
     const int floor_sp = rfl(W.floor_sp);
-    defer_t0 = rfl(defer_t0);
+    defer_t0 = rfl(defer_t0); grow_shift = rfl(grow_shift);
     const float eps = RAY_EPSILON;
     const unsigned long long nodes = rfl64((unsigned long long)W.nodes), tris = rfl64((unsigned long long)W.tris);
     float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;          // triangle-test temporaries
@@ -400,7 +400,7 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
         // the threshold grows with the length of the walk, so a packet that turns out incoherent converts itself to per-lane work
         "s_add_i32 %[steps], %[steps], 1\n\t"
         "s_bcnt1_i32_b64 s89, %[m]\n\t"
-        "s_lshr_b32 s90, %[steps], 3\n\t"
+        "s_lshr_b32 s90, %[steps], %[gsh]\n\t"
         "s_add_i32 s90, s90, %[t0d]\n\t"
         "s_cmp_le_u32 s89, s90\n\t"
         "s_cbranch_scc1 PKB_DEFER_%=\n\t"
@@ -598,7 +598,7 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
         : [nodes] "s"(nodes), [tris] "s"(tris), [floor] "s"(floor_sp),
           [oxy] "v"(W.ray.o_xy), [ozz] "v"(W.ray.o_zz), [ixy] "v"(W.ray.i_xy), [izz] "v"(W.ray.i_zz), [tcur] "v"(W.ray.tcur),
           [ox] "v"(W.ray.o_xy.x), [oy] "v"(W.ray.o_xy.y), [oz] "v"(W.ray.o_zz.x), [dx] "v"(W.ray.d.x), [dy] "v"(W.ray.d.y), [dz] "v"(W.ray.d.z),
-          [eps] "s"(eps), [t0d] "s"(defer_t0), [llds] "v"(lane_lds)
+          [eps] "s"(eps), [t0d] "s"(defer_t0), [gsh] "s"(grow_shift), [llds] "v"(lane_lds)
         : "vcc", "scc", "m0", "memory",
           "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
           "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
@@ -607,7 +607,7 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
     if (maxd + 2 > stack_size || err) W.err = 1;       // reference stack: `depth` pending + 2 pushed at the deepest inner node expanded
 }
 
-struct PkHybrid { int * stk; uint32_t lane_lds; int * spill; int spill_stride; int t0; };
+struct PkHybrid { int * stk; uint32_t lane_lds; int * spill; int spill_stride; int t0, grow; };
 
 // ---- hybrid any-hit walk, per-lane phase -----------------------------------------------------------------------------------------
 // Walks the subtrees the packet walk handed to the lanes' private stacks (entries are nodes that already passed the lane's slab test,
@@ -795,7 +795,7 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
                 // the whole BLAS walk, hand-scheduled (returns with m == 0), then the per-lane phase over what it deferred
                 PK_T0();
                 W.psp = 0;
-                pk_blas_any_asm(W, sc.stack_size, H.lane_lds, H.t0);
+                pk_blas_any_asm(W, sc.stack_size, H.lane_lds, H.t0, H.grow);
                 PK_T1(1);
                 if (W.alive != 0ull && __ballot(W.psp > 0) != 0ull) { PK_T0(); pk_lane_phase_any(W, lane, H.stk, H.spill, H.spill_stride, RTX_GPTR(B.nodes), RTX_GPTR(B.tri_hot)); PK_T1(2); }
             }
@@ -825,7 +825,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
     H.lane_lds = (uint32_t)(uintptr_t)H.stk;
     H.spill_stride = q.spill_threads;
     H.spill = q.spill + 2 * (size_t)q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) + (blockIdx.x * blockDim.x + threadIdx.x);
-    H.t0 = q.pk_defer_t0;
+    H.t0 = q.pk_defer_t0; H.grow = q.pk_defer_grow;
     const uint32_t gwave  = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
     const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE);
 

@@ -18,8 +18,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         g = {}
         for n, ms in kt: g.setdefault(n, []).append(ms)
         out.append({k: round(float(np.sum(v)) / 10, 4) for k, v in g.items()})
-    print("T0=%s parity=%s packet=%s lane=%s" % (os.environ.get("RTX_PK_DEFER"), same, out[0], out[1]), flush=True)
+    print("T0=%s grow=%s scale=%s lib=%s parity=%s any=%.4f (lane %.4f)" % (os.environ.get("RTX_PK_DEFER"), os.environ.get("RTX_PK_GROW"), os.environ.get("RTX_PK_GRID_SCALE"), os.path.basename(os.environ.get("RTX_HIP_LIB", "default")), same, out[0]["k_trace_any"], out[1]["k_trace_any"]), flush=True)
 else:
-    for t in sys.argv[1:] or ["0", "4", "8", "16", "32", "64"]:
-        env = dict(os.environ, RTX_PK_DEFER=t)
+    # arguments: T0:grow[:gridscale[:libvariant]] ...
+    for spec in sys.argv[1:] or ["8:3"]:
+        f = spec.split(":")
+        env = dict(os.environ, RTX_PK_DEFER=f[0], RTX_PK_GROW=f[1] if len(f) > 1 else "3")
+        if len(f) > 2 and f[2]: env["RTX_PK_GRID_SCALE"] = f[2]
+        if len(f) > 3 and f[3]: env["RTX_HIP_LIB"] = os.path.join(HERE, "..", "cpu-raytracer_amd", "csrc", "librtx_hip_%s.so" % f[3])
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, timeout=300)
