@@ -230,7 +230,17 @@ def main():
         sl.r.bind_framebuffer(sl.fb_rgb.data_ptr(), sl.fb_packed.data_ptr())
         sl.stream = torch.cuda.current_stream() if nfl == 1 else torch.cuda.Stream()
         sl.r.set_stream(sl.stream.cuda_stream)
-        sl.gather = shard.TileGather(W, H, rank, world, "cuda") if (world > 1 or args.force_gather) else None
+        sl.gather = None
+        if world > 1 or args.force_gather:
+            # multi-GPU path of the C ABI (include/rtx.h rtx_group_*): RCCL is called by librtx_hip.so itself; torch.distributed only
+            # carries the 128-byte communicator id from rank 0 to the other ranks (and the barrier / max-over-ranks of the timing contract)
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(api.Renderer.group_unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(uid, src=0)
+            sl.r.group_create(rank, world, bytes(uid.cpu().numpy().tobytes()))
+            sl.gather = True
         slots.append(sl)
     r, fb_rgb, fb_packed, gather = slots[0].r, slots[0].fb_rgb, slots[0].fb_packed, slots[0].gather
     frame_no = [0]
@@ -238,10 +248,10 @@ def main():
     def step():
         sl = slots[frame_no[0] % nfl]
         frame_no[0] += 1
-        sl.r.render_async(first, stride, count, simple_trace=args.simple_trace, cull_dead_shadow_rays=args.cull, serial=serial)
         if sl.gather is not None:
-            with torch.cuda.stream(sl.stream):
-                sl.gather(sl.fb_packed)
+            sl.r.group_render(cull_dead_shadow_rays=args.cull)            # this rank's tiles + ncclGather + frame assembly on rank 0, one stream
+        else:
+            sl.r.render_async(first, stride, count, simple_trace=args.simple_trace, cull_dead_shadow_rays=args.cull, serial=serial)
 
     def sync():
         torch.cuda.synchronize()
@@ -305,9 +315,10 @@ def main():
     # the gathered frame on rank 0 must equal a frame rendered by rank 0 alone (untimed check)
     gather_ok = None
     if gather is not None and rank == 0:
+        gathered = fb_packed.clone()                    # rank 0's packed framebuffer holds the assembled frame of the last group render
         r.render_async(0, 1, T)
         torch.cuda.synchronize()
-        gather_ok = bool(torch.equal(gather.final, fb_packed))
+        gather_ok = bool(torch.equal(gathered, fb_packed))
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -376,7 +387,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "width": W, "height": H, "bounces": int(sc.config["bounces"][0]),
                        "triangles": sc.triangle_refs(), "bvh_nodes": int(sum(len(b.nodes) for b in sc.blas)),
-                       "frames_in_flight": nfl, "streams_per_frame": 1 if serial else 2, "tiles": T, "sharding": "tile t -> GPU t mod N; RCCL gather of packed tiles to rank 0" if world > 1 else "single GPU"},
+                       "frames_in_flight": nfl, "streams_per_frame": 1 if serial else 2, "tiles": T, "sharding": "tile t -> GPU t mod N, tile-major buffers, one ncclGather per frame to rank 0 (rtx_group_render)" if world > 1 else "single GPU"},
             "rays_per_frame": {"primary": tot[0], "shadow": tot[1], "reflection": tot[2], "refraction": tot[3], "total": tot[4]},
             "mprimary_per_s": round(tot[0] / (ms_per_step * 1e-3) * 1e-6, 3),
             "kernels": kern,

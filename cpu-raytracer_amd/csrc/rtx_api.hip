@@ -498,7 +498,14 @@ static void launch_timed(rtx_ctx * c, const char * name, hipStream_t stream, F &
     } else launch();
 }
 
+static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_stride, int32_t tile_count, uint32_t flags, uint32_t * tile_major);
+
 extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_stride, int32_t tile_count, uint32_t flags) {
+    return render_tiles_impl(c, first_tile, tile_stride, tile_count, flags, nullptr);
+}
+
+// tile_major != nullptr: the packed level-0 pixels of the i-th rendered tile go to tile_major[i * 1024 ...] (slot order) instead of the framebuffer
+static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_stride, int32_t tile_count, uint32_t flags, uint32_t * tile_major) {
     if (!c || first_tile < 0 || tile_stride < 1 || tile_count < 0) return RTX_ERR_INVALID_ARG;
     if (!c->frame_set) { c->err = "rtx_render_tiles before rtx_set_frame"; return RTX_ERR_STATE; }
     if (int bad = validate_references(c)) return bad;
@@ -529,6 +536,7 @@ extern "C" int rtx_render_tiles(rtx_ctx * c, int32_t first_tile, int32_t tile_st
         const int n = (tile_count - done) < batch_tiles ? (tile_count - done) : batch_tiles;
         DevQueues q = c->q;
         q.first_tile = first_tile + done * tile_stride; q.tile_stride = tile_stride; q.tile_count = n; q.primary_slots = n * 1024;
+        q.tm_packed = tile_major; q.tm_base = done * 1024;
         const DevScene sc = c->scene;
         const bool plain = count_work || simple || sc.heatmap;
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, q.counters, q.pk_heads, (uint32_t)q.primary_slots,
@@ -789,4 +797,185 @@ extern "C" int rtx_debug_sky_sample(rtx_ctx * c, const float * dirs3, float * ou
     HIP_OK(c, hipMemcpy(out3, dout, (size_t)n * 12, hipMemcpyDeviceToHost));
     hipFree(din); hipFree(dout);
     return RTX_OK;
+}
+
+
+// ---- GPU groups: screen tiles sharded over the GPUs of one node, RCCL gather of the packed tiles to rank 0 -----------
+// RCCL is bound at run time (dlopen): librtx_hip.so has no link-time dependency on it, and a process that already carries an RCCL
+// (e.g. PyTorch's) gets that same copy.
+#include <dlfcn.h>
+typedef struct { char internal[128]; } rtx_nccl_id;
+typedef void * rtx_nccl_comm;
+struct RcclApi {
+    void * lib = nullptr;
+    int (*GetUniqueId)(rtx_nccl_id *) = nullptr;
+    int (*CommInitRank)(rtx_nccl_comm *, int, rtx_nccl_id, int) = nullptr;
+    int (*CommInitAll)(rtx_nccl_comm *, int, const int *) = nullptr;
+    int (*CommDestroy)(rtx_nccl_comm) = nullptr;
+    int (*Gather)(const void *, void *, size_t, int, int, rtx_nccl_comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char * (*GetErrorString)(int) = nullptr;
+};
+static RcclApi * rccl() {
+    static RcclApi api; static bool tried = false;
+    if (tried) return api.lib ? &api : nullptr;
+    tried = true;
+    const char * names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char * n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.lib) break; }
+    if (!api.lib) return nullptr;
+    bool ok = true;
+    auto sym = [&](const char * n) { void * p = dlsym(api.lib, n); if (!p) ok = false; return p; };
+    api.GetUniqueId = (int (*)(rtx_nccl_id *))sym("ncclGetUniqueId");
+    api.CommInitRank = (int (*)(rtx_nccl_comm *, int, rtx_nccl_id, int))sym("ncclCommInitRank");
+    api.CommInitAll = (int (*)(rtx_nccl_comm *, int, const int *))sym("ncclCommInitAll");
+    api.CommDestroy = (int (*)(rtx_nccl_comm))sym("ncclCommDestroy");
+    api.Gather = (int (*)(const void *, void *, size_t, int, int, rtx_nccl_comm, hipStream_t))sym("ncclGather");
+    api.GroupStart = (int (*)())sym("ncclGroupStart");
+    api.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    api.GetErrorString = (const char * (*)(int))sym("ncclGetErrorString");
+    if (!ok) { dlclose(api.lib); api.lib = nullptr; return nullptr; }
+    return &api;
+}
+
+struct rtx_group {
+    rtx_ctx * ctx = nullptr;
+    int rank = 0, world = 1, tiles_total = 0, tiles_per_rank = 0, own_tiles = 0;
+    rtx_nccl_comm comm = nullptr;
+    DevBuf send, recv;           // tile-major packed pixels: this rank's tiles; on rank 0 every rank's
+};
+
+static int group_setup(rtx_group * g) {
+    rtx_ctx * c = g->ctx;
+    const int tcx = (c->cfg.width + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE, tcy = (c->cfg.height + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE;
+    g->tiles_total = tcx * tcy;
+    g->tiles_per_rank = (g->tiles_total + g->world - 1) / g->world;          // padded: every rank sends the same count
+    g->own_tiles = g->rank < g->tiles_total ? (g->tiles_total - g->rank + g->world - 1) / g->world : 0;
+    hipSetDevice(c->cfg.device);
+    int rc = ensure(c, g->send, (size_t)g->tiles_per_rank * 1024 * 4);
+    if (!rc && g->rank == 0) rc = ensure(c, g->recv, (size_t)g->world * g->tiles_per_rank * 1024 * 4);
+    if (!rc) hipMemset(g->send.p, 0, (size_t)g->tiles_per_rank * 1024 * 4);
+    return rc;
+}
+
+extern "C" int rtx_group_unique_id(void * id128) {
+    if (!id128) return RTX_ERR_INVALID_ARG;
+    RcclApi * r = rccl();
+    if (!r) return RTX_ERR_STATE;
+    rtx_nccl_id id;
+    if (r->GetUniqueId(&id) != 0) return RTX_ERR_HIP;
+    memcpy(id128, &id, sizeof(id));
+    return RTX_OK;
+}
+
+extern "C" int rtx_group_create(rtx_ctx * c, int32_t rank, int32_t world, const void * id128, rtx_group ** out) {
+    if (!c || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return RTX_ERR_INVALID_ARG;
+    *out = nullptr;
+    rtx_group * g = new rtx_group();
+    g->ctx = c; g->rank = rank; g->world = world;
+    RcclApi * r = rccl();
+    if (!r) { c->err = "RCCL (librccl.so.1) could not be loaded"; delete g; return RTX_ERR_STATE; }
+    hipSetDevice(c->cfg.device);
+    rtx_nccl_id id; memset(&id, 0, sizeof(id));
+    if (id128) memcpy(&id, id128, sizeof(id)); else if (r->GetUniqueId(&id) != 0) { delete g; return RTX_ERR_HIP; }
+    const int e = r->CommInitRank(&g->comm, world, id, rank);
+    if (e != 0) { c->err = std::string("ncclCommInitRank: ") + r->GetErrorString(e); delete g; return RTX_ERR_HIP; }
+    const int rc = group_setup(g);
+    if (rc) { r->CommDestroy(g->comm); delete g; return rc; }
+    *out = g;
+    return RTX_OK;
+}
+
+// One process driving n GPUs (the shape of the reference's own main loop): contexts[i] lives on its own device and becomes rank i.
+extern "C" int rtx_group_create_local(rtx_ctx ** contexts, int32_t n, rtx_group ** out_groups) {
+    if (!contexts || !out_groups || n < 1 || n > 64) return RTX_ERR_INVALID_ARG;
+    RcclApi * r = rccl();
+    if (!r) return RTX_ERR_STATE;
+    std::vector<int> devs(n); std::vector<rtx_nccl_comm> comms(n, nullptr);
+    for (int i = 0; i < n; i++) { if (!contexts[i]) return RTX_ERR_INVALID_ARG; devs[i] = contexts[i]->cfg.device; out_groups[i] = nullptr; }
+    const int e = r->CommInitAll(comms.data(), n, devs.data());
+    if (e != 0) { contexts[0]->err = std::string("ncclCommInitAll: ") + r->GetErrorString(e); return RTX_ERR_HIP; }
+    for (int i = 0; i < n; i++) {
+        rtx_group * g = new rtx_group();
+        g->ctx = contexts[i]; g->rank = i; g->world = n; g->comm = comms[i];
+        const int rc = group_setup(g);
+        if (rc) { delete g; return rc; }
+        out_groups[i] = g;
+    }
+    return RTX_OK;
+}
+
+static int group_render_one(rtx_group * g, uint32_t flags, bool render, bool gather, bool finish) {
+    rtx_ctx * c = g->ctx;
+    RcclApi * r = rccl();
+    hipSetDevice(c->cfg.device);
+    if (render) {
+        const int rc = render_tiles_impl(c, g->rank, g->world, g->own_tiles, flags | RTX_RENDER_SERIAL, (uint32_t *)g->send.p);
+        if (rc) return rc;
+    }
+    if (gather) {
+        // the one exchange of a frame: every rank's tiles_per_rank * 4 KiB of packed pixels to rank 0, on the stream the frame was rendered on
+        const int e = r->Gather(g->send.p, g->recv.p, (size_t)g->tiles_per_rank * 1024, /*ncclUint32*/ 3, 0, g->comm, c->stream);
+        if (e != 0) { c->err = std::string("ncclGather: ") + r->GetErrorString(e); return RTX_ERR_HIP; }
+    }
+    if (finish && g->rank == 0) {
+        const int tcx = (c->cfg.width + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE;
+        hipLaunchKernelGGL(k_unswizzle, dim3(c->n_cu * 4), dim3(256), 0, c->stream, (const uint32_t *)g->recv.p,
+                           (uint32_t *)(c->ext_packed ? c->ext_packed : c->d_fb_packed.p), g->world, g->tiles_per_rank, g->tiles_total, tcx, c->cfg.width, c->cfg.height);
+        HIP_OK(c, hipGetLastError());
+    }
+    return RTX_OK;
+}
+
+// Renders this rank's tile shard (tile t belongs to rank t mod world, WorkerThread.cpp:53-65 without the atomic counter), gathers the
+// packed tiles to rank 0 and, there, writes the frame into the context's packed framebuffer.  Everything is queued on the context's
+// stream; nothing synchronises with the host.
+extern "C" int rtx_group_render(rtx_group * g, uint32_t flags) {
+    if (!g || !g->ctx) return RTX_ERR_INVALID_ARG;
+    return group_render_one(g, flags, true, true, true);
+}
+
+extern "C" int rtx_group_render_local(rtx_group ** groups, int32_t n, uint32_t flags) {
+    if (!groups || n < 1) return RTX_ERR_INVALID_ARG;
+    RcclApi * r = rccl();
+    if (!r) return RTX_ERR_STATE;
+    for (int i = 0; i < n; i++) { if (!groups[i]) return RTX_ERR_INVALID_ARG; const int rc = group_render_one(groups[i], flags, true, false, false); if (rc) return rc; }
+    r->GroupStart();                                               // one thread issues every rank's call of the collective
+    int rc = RTX_OK;
+    for (int i = 0; i < n && !rc; i++) rc = group_render_one(groups[i], flags, false, true, false);
+    r->GroupEnd();
+    for (int i = 0; i < n && !rc; i++) rc = group_render_one(groups[i], flags, false, false, true);
+    return rc;
+}
+
+extern "C" int rtx_group_destroy(rtx_group * g) {
+    if (!g) return RTX_ERR_INVALID_ARG;
+    if (g->ctx) { hipSetDevice(g->ctx->cfg.device); if (g->ctx->stream) hipStreamSynchronize(g->ctx->stream); }
+    if (g->comm) { RcclApi * r = rccl(); if (r) r->CommDestroy(g->comm); }
+    if (g->send.p) hipFree(g->send.p);
+    if (g->recv.p) hipFree(g->recv.p);
+    delete g;
+    return RTX_OK;
+}
+
+// Test hook: the whole group path of `world` ranks on ONE GPU without RCCL — every rank's tile shard rendered tile-major straight into
+// its slice of rank 0's receive buffer, then the same k_unswizzle.  Covers the partition, the tile-major writes and the frame assembly
+// for any world size; the ncclGather itself is exercised by rtx_group_render.
+extern "C" int rtx_debug_group_loopback(rtx_ctx * c, int32_t world, uint32_t flags) {
+    if (!c || world < 1) return RTX_ERR_INVALID_ARG;
+    rtx_group g; g.ctx = c; g.rank = 0; g.world = world;
+    int rc = group_setup(&g);
+    for (int r = 0; r < world && !rc; r++) {
+        const int own = r < g.tiles_total ? (g.tiles_total - r + world - 1) / world : 0;
+        rc = render_tiles_impl(c, r, world, own, flags | RTX_RENDER_SERIAL, (uint32_t *)g.recv.p + (size_t)r * g.tiles_per_rank * 1024);
+    }
+    if (!rc) {
+        const int tcx = (c->cfg.width + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE;
+        hipLaunchKernelGGL(k_unswizzle, dim3(c->n_cu * 4), dim3(256), 0, c->stream, (const uint32_t *)g.recv.p,
+                           (uint32_t *)(c->ext_packed ? c->ext_packed : c->d_fb_packed.p), world, g.tiles_per_rank, g.tiles_total, tcx, c->cfg.width, c->cfg.height);
+        hipStreamSynchronize(c->stream);
+    }
+    if (g.send.p) hipFree(g.send.p);
+    if (g.recv.p) hipFree(g.recv.p);
+    return rc;
 }

@@ -128,6 +128,8 @@ struct DevQueues {
     int32_t       pk_defer_t0;    // hybrid any-hit walk: nodes wanted by at most this many lanes (+ walk length / 8) go to the lanes' private stacks
     DevCounters * counters;
     uint32_t *    pk_heads;       // packet-queue heads of the packet kernels: [closest | any][level][8 heads], 128 bytes apart (rtx_packet.h)
+    uint32_t *    tm_packed;      // group rendering: level-0 pixels go, packed, to tm_packed[tm_base + primary slot] (tile-major) instead of the raster framebuffer
+    int32_t       tm_base;
     float *       fb_rgb;         // W*H*3
     uint32_t *    fb_packed;      // W*H
 };

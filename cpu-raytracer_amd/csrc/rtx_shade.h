@@ -511,7 +511,9 @@ void k_resolve(const DevScene sc, const DevQueues q, const int level) {
             colour = result;
             distance = n2.w;
         }
-        if (level == 0) {
+        if (level == 0 && q.tm_packed) {
+            q.tm_packed[(uint32_t)q.tm_base + idx] = plot_pack(colour);        // tile-major: slot order, one coalesced store per wave
+        } else if (level == 0) {
             const int pixel = as_i(n3.y);
             q.fb_rgb[3 * (size_t)pixel + 0] = colour.x;
             q.fb_rgb[3 * (size_t)pixel + 1] = colour.y;
@@ -523,5 +525,22 @@ void k_resolve(const DevScene sc, const DevQueues q, const int level) {
             if (parent & 0x80000000u) q.c1[ps] = make_float4(colour.x, colour.y, colour.z, distance);
             else                      q.c0[ps] = make_float4(colour.x, colour.y, colour.z, 0.0f);
         }
+    }
+}
+
+// Root of a GPU group: the gathered tile-major buffers of all ranks (rank r's k-th tile = tile r + k * world, 1024 slots each, slot
+// order of primary_pixel) -> raster framebuffer.  One thread per slot; clipped slots of edge tiles are skipped.
+__global__ __launch_bounds__(256)
+void k_unswizzle(const uint32_t * gathered, uint32_t * fb_packed, int world, int tiles_per_rank, int tile_count, int tile_count_x, int width, int height) {
+    const uint32_t total = (uint32_t)world * (uint32_t)tiles_per_rank * 1024u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t rk = i >> 10, l = i & 1023u;
+        const int r = (int)(rk / (uint32_t)tiles_per_rank), k = (int)(rk % (uint32_t)tiles_per_rank);
+        const int tile = r + k * world;                                   // WorkerThread.cpp:57-61 numbering, tile t belongs to GPU t mod N
+        if (tile >= tile_count) continue;
+        const int tx = (tile % tile_count_x) * RTX_TILE_SIZE, ty = (tile / tile_count_x) * RTX_TILE_SIZE;
+        const int blk = (int)(l >> 6), ln = (int)(l & 63u);
+        const int px = tx + (blk & 3) * 8 + (ln & 7), py = ty + (blk >> 2) * 8 + (ln >> 3);
+        if (px < width && py < height) fb_packed[(size_t)py * width + px] = gathered[i];
     }
 }

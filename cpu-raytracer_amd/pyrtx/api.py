@@ -20,7 +20,9 @@ LIB_PATH = os.path.join(_HERE, "..", "csrc", "librtx_hip.so")
 EXPORTS = ["rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_blas", "rtx_upload_materials",
            "rtx_upload_texture", "rtx_upload_sky", "rtx_set_frame", "rtx_render_tiles", "rtx_synchronize", "rtx_get_stats",
            "rtx_read_framebuffer", "rtx_framebuffer_device_ptrs", "rtx_last_kernel_times", "rtx_enable_kernel_timing",
-           "rtx_bind_framebuffer", "rtx_set_stream", "rtx_present", "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample"]
+           "rtx_bind_framebuffer", "rtx_set_stream", "rtx_present", "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample",
+           "rtx_group_unique_id", "rtx_group_create", "rtx_group_render", "rtx_group_destroy", "rtx_group_create_local", "rtx_group_render_local",
+           "rtx_debug_group_loopback"]
 
 RTX_RENDER_COUNT_WORK = 1
 RTX_RENDER_SIMPLE_TRACE = 2
@@ -72,6 +74,13 @@ def load_library(path: Optional[str] = None):
     lib.rtx_debug_libm.argtypes = [vp, i32, vp, vp, vp, i32]
     lib.rtx_debug_texture_sample.argtypes = [vp, i32, vp, vp, i32]
     lib.rtx_debug_sky_sample.argtypes = [vp, vp, vp, i32]
+    lib.rtx_group_unique_id.argtypes = [vp]
+    lib.rtx_group_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    lib.rtx_group_render.argtypes = [vp, u32]
+    lib.rtx_group_destroy.argtypes = [vp]
+    lib.rtx_group_create_local.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
+    lib.rtx_group_render_local.argtypes = [C.POINTER(vp), i32, u32]
+    lib.rtx_debug_group_loopback.argtypes = [vp, i32, u32]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("rtx_last_error",):
@@ -104,6 +113,8 @@ class Renderer:
             raise RtxError(rc, where, (self.lib.rtx_last_error(self.ctx) or b"").decode())
 
     def close(self):
+        if self.ctx and getattr(self, "group", None):
+            self.group_destroy()
         if self.ctx:
             self.lib.rtx_destroy(self.ctx)
             self.ctx = None
@@ -194,6 +205,31 @@ class Renderer:
         names = (C.c_char_p * cap)(); ms = (C.c_float * cap)(); n = C.c_int32()
         self._chk(self.lib.rtx_last_kernel_times(self.ctx, names, ms, cap, C.byref(n)), "rtx_last_kernel_times")
         return [(names[i].decode(), float(ms[i])) for i in range(min(n.value, cap))]
+
+    # ---- GPU groups (include/rtx.h: rtx_group_*) ----------------------------------------------------------------
+    @staticmethod
+    def group_unique_id() -> bytes:
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.rtx_group_unique_id(buf)
+        if rc:
+            raise RtxError(rc, "rtx_group_unique_id")
+        return buf.raw
+
+    def group_create(self, rank: int, world: int, unique_id: Optional[bytes] = None):
+        self.group = C.c_void_p()
+        self._chk(self.lib.rtx_group_create(self.ctx, rank, world, unique_id, C.byref(self.group)), "rtx_group_create")
+
+    def group_render(self, cull_dead_shadow_rays: bool = False, lane_trace: bool = False):
+        flags = (RTX_RENDER_CULL_DEAD_SHADOW_RAYS if cull_dead_shadow_rays else 0) | (RTX_RENDER_LANE_TRACE if lane_trace else 0)
+        self._chk(self.lib.rtx_group_render(self.group, flags), "rtx_group_render")
+
+    def group_destroy(self):
+        if getattr(self, "group", None):
+            self.lib.rtx_group_destroy(self.group); self.group = None
+
+    def group_loopback(self, world: int, flags: int = 0):
+        self._chk(self.lib.rtx_debug_group_loopback(self.ctx, world, flags), "rtx_debug_group_loopback")
 
     # ---- unit-level hooks ---------------------------------------------------------------------------
     def debug_libm(self, fn: int, a: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:

@@ -316,6 +316,29 @@ int rtx_set_stream(rtx_ctx * ctx, void * hip_stream);
 int rtx_last_kernel_times(rtx_ctx * ctx, const char ** names, float * ms, int32_t capacity, int32_t * count);
 int rtx_enable_kernel_timing(rtx_ctx * ctx, int32_t enable);
 
+/* ---- several GPUs of one node (BASELINE configs[3]) ------------------------------------------------------
+ * The reference hands 32x32 screen tiles to worker threads through an atomic counter (WorkerThread.cpp:53-65,
+ * 116-129); tiles are independent given the read-only Scene.  A GPU group does the same across GPUs: tile t
+ * belongs to rank t mod world, every rank renders its tiles into a TILE-MAJOR buffer of packed pixels (edge
+ * tiles padded to 32x32), ONE RCCL gather per frame moves those buffers to rank 0 over xGMI, and rank 0 writes
+ * them into its packed framebuffer (rtx_read_framebuffer / rtx_framebuffer_device_ptrs on rank 0's context).
+ * Every rank uploads the same scene and calls rtx_set_frame with the same frame (Scene::update runs on every
+ * host, or its result is sent: < 4 KiB).  All calls of a group are collective: every rank makes them in the
+ * same order.  RCCL (librccl.so.1) is loaded at run time; without it these functions return RTX_ERR_STATE.   */
+typedef struct rtx_group rtx_group;
+#define RTX_GROUP_ID_BYTES 128
+/* rank 0: a fresh communicator id (ncclGetUniqueId) to hand to the other ranks by any out-of-band channel */
+int rtx_group_unique_id(void * id128);
+/* one context per process: rank `rank` of `world` joins the group (id128 may be NULL when world == 1) */
+int rtx_group_create(rtx_ctx * ctx, int32_t rank, int32_t world, const void * id128, rtx_group ** out_group);
+/* this rank's share of one frame + gather + (rank 0) frame assembly; queued on the context's stream, returns at once.
+ * flags as rtx_render_tiles (RTX_RENDER_SERIAL is implied).  rtx_get_stats afterwards covers this rank's tiles. */
+int rtx_group_render(rtx_group * group, uint32_t flags);
+int rtx_group_destroy(rtx_group * group);
+/* one process driving n GPUs, contexts[i] on its own device = rank i (ncclCommInitAll); render issues all ranks' calls */
+int rtx_group_create_local(rtx_ctx ** contexts, int32_t n, rtx_group ** out_groups);
+int rtx_group_render_local(rtx_group ** groups, int32_t n, uint32_t flags);
+
 /* ---- unit-level entry points: one reference function each, evaluated on the device -------------
  * (used by the parity tests; not needed by a renderer)                                          */
 
@@ -323,6 +346,8 @@ int rtx_enable_kernel_timing(rtx_ctx * ctx, int32_t enable);
 int rtx_debug_libm(rtx_ctx * ctx, int32_t fn, const float * a, const float * b, float * out, int32_t n);
 /* Texture::sample (Texture.h:33-49) of an uploaded texture at n inputs (s,t,ds_dx,ds_dy,dt_dx,dt_dy) */
 int rtx_debug_texture_sample(rtx_ctx * ctx, int32_t texture_id, const float * in6, float * out_rgb, int32_t n);
+/* the group path of `world` ranks replayed on this one GPU without RCCL (partition, tile-major writes, frame assembly) */
+int rtx_debug_group_loopback(rtx_ctx * ctx, int32_t world, uint32_t flags);
 /* Sky::sample (Sky.cpp:28-68) of the uploaded sky at n directions */
 int rtx_debug_sky_sample(rtx_ctx * ctx, const float * directions_xyz, float * out_rgb, int32_t n);
 

@@ -229,3 +229,32 @@ def test_stack_size_knob_is_honoured(api):
         with pytest.raises(api.RtxError) as e:
             api.Renderer(sc).render(**MODES[mode])
         assert e.value.code == 4, mode
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("name", ["materials_aniso", "monkey_small"])
+def test_group_path_loopback_equals_single_gpu_frame(api, name, world):
+    """include/rtx.h rtx_group_*: tile t -> rank t mod world, tile-major packed buffers, frame assembly on rank 0 — replayed for `world`
+    ranks on one GPU (rtx_debug_group_loopback: everything but the ncclGather itself).  monkey_small is 301-pixel-ragged below."""
+    sc, _ = util.load_golden(name)
+    if name == "monkey_small":
+        sc.config["width"] = 301; sc.config["height"] = 173            # edge tiles clipped in both directions
+    full = api.Renderer(sc).render()
+    r = api.Renderer(sc)
+    r.group_loopback(world)
+    _, packed = r.framebuffer()
+    assert np.array_equal(packed, full["packed"])
+
+
+def test_group_render_one_rank_over_rccl(api):
+    """rtx_group_create / rtx_group_render with world == 1: the real RCCL communicator and ncclGather (to itself), through the C ABI."""
+    sc, _ = util.load_golden("materials_aniso")
+    full = api.Renderer(sc).render()
+    r = api.Renderer(sc)
+    r.group_create(0, 1, api.Renderer.group_unique_id())
+    for _ in range(2):
+        r.group_render()
+    st, _ = r.stats()
+    _, packed = r.framebuffer()
+    assert np.array_equal(packed, full["packed"]) and st == full["stats"]
+    r.group_destroy()
