@@ -54,7 +54,11 @@ struct rtx_ctx {
     // host copies for validate_references(): every id a kernel will follow is checked on the host before anything is launched
     std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true;
 
-    DevBuf f_tlas, f_tlas_pk, f_tlas_idx, f_inst, f_sph, f_pln, f_pl, f_sl, f_dl;
+    // per-frame state (rtx_set_frame): ONE device block, filled by one asynchronous copy on the context's stream from a ring of pinned
+    // staging buffers — the host never waits for the GPU between frames (cfg5: Scene::update + TLAS rebuild every frame)
+    DevBuf d_frame;
+    struct FrameStage { void * host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; } stage[3];
+    int stage_next = 0;
     DevScene scene;
     bool frame_set = false;
 
@@ -207,13 +211,13 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto & v : c->blas_allocs) for (void * p : v) hipFree(p);
-    for (void * p : c->tex_allocs) hipFree(p);
-    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->f_tlas, &c->f_tlas_pk, &c->f_tlas_idx, &c->f_inst, &c->f_sph,
-                        &c->f_pln, &c->f_pl, &c->f_sl, &c->f_dl, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads };
+    for (void * p : c->tex_allocs) if (p) hipFree(p);
+    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->d_frame, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads };
     for (DevBuf * b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf & b : c->qb) if (b.p) hipFree(b.p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     for (DevCounters * h : c->pending_host) hipHostFree(h);
+    for (auto & st : c->stage) { if (st.host) hipHostFree(st.host); if (st.done) hipEventDestroy(st.done); }
     if (c->any_stream) { hipStreamSynchronize(c->any_stream); hipStreamDestroy(c->any_stream); }
     if (c->ev_shade0) hipEventDestroy(c->ev_shade0);
     if (c->ev_shade_last) hipEventDestroy(c->ev_shade_last);
@@ -309,6 +313,10 @@ extern "C" int rtx_upload_texture(rtx_ctx * c, int32_t texture_id, const rtx_tex
     if ((size_t)texture_id >= c->h_tex.size()) { size_t old = c->h_tex.size(); c->h_tex.resize(texture_id + 1); for (size_t i = old; i < c->h_tex.size(); i++) memset(&c->h_tex[i], 0, sizeof(DevTexture)); }
     void * d = nullptr;
     HIP_OK(c, hipMalloc(&d, (size_t)texel_count * 12));
+    if (c->h_tex[texture_id].texels) {            // re-upload of an id: the old texel array is released (after the frames that may still read it)
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        for (void *& p : c->tex_allocs) if (p == (void *)c->h_tex[texture_id].texels) { hipFree(p); p = nullptr; }
+    }
     c->tex_allocs.push_back(d);
     HIP_OK(c, hipMemcpy(d, texels_rgb, (size_t)texel_count * 12, hipMemcpyHostToDevice));
     c->h_tex[texture_id].desc = *desc;
@@ -344,18 +352,34 @@ extern "C" int rtx_set_frame(rtx_ctx * c, const rtx_frame * f) {
         const int b = f->instances[i].blas_id;
         if (b < 0 || (size_t)b >= c->h_blas.size() || !c->h_blas[b].nodes) return RTX_ERR_STATE;
     }
-    if (c->stream) hipStreamSynchronize(c->stream);      // never concurrently with rendering (Main.cpp:54-57)
-
-    std::vector<float4> nd; convert_nodes(f->tlas_nodes, f->tlas_node_count, nd);
-    int rc = upload(c, c->f_tlas, nd.data(), nd.size() * 16);
-    if (!rc) { std::vector<float4> ndp; convert_nodes_pk(f->tlas_nodes, f->tlas_node_count, ndp); rc = upload(c, c->f_tlas_pk, ndp.data(), ndp.size() * 16); }
-    if (!rc) rc = upload(c, c->f_tlas_idx, f->tlas_indices, (size_t)f->tlas_index_count * 4);
-    if (!rc) rc = upload(c, c->f_inst, f->instances, (size_t)f->instance_count * sizeof(rtx_instance));
-    if (!rc) rc = upload(c, c->f_sph, f->spheres, (size_t)f->sphere_count * sizeof(rtx_sphere));
-    if (!rc) rc = upload(c, c->f_pln, f->planes, (size_t)f->plane_count * sizeof(rtx_plane));
-    if (!rc) rc = upload(c, c->f_pl, f->point_lights, (size_t)f->point_light_count * sizeof(rtx_point_light));
-    if (!rc) rc = upload(c, c->f_sl, f->spot_lights, (size_t)f->spot_light_count * sizeof(rtx_spot_light));
-    if (!rc) rc = upload(c, c->f_dl, f->directional_lights, (size_t)f->directional_light_count * sizeof(rtx_directional_light));
+    // Pack the frame into one block: [TLAS nodes, lane layout][TLAS nodes, packet layout][indices][instances][spheres][planes][lights],
+    // every part 256-byte aligned.  The block is staged in pinned memory and copied by ONE hipMemcpyAsync on the context's stream: it is
+    // ordered after the frames already queued there (which still read the previous contents) and before the next render call.
+    std::vector<float4> nd, ndp; convert_nodes(f->tlas_nodes, f->tlas_node_count, nd); convert_nodes_pk(f->tlas_nodes, f->tlas_node_count, ndp);
+    const void * src[9] = { nd.data(), ndp.data(), f->tlas_indices, f->instances, f->spheres, f->planes, f->point_lights, f->spot_lights, f->directional_lights };
+    const size_t len[9] = { nd.size() * 16, ndp.size() * 16, (size_t)f->tlas_index_count * 4, (size_t)f->instance_count * sizeof(rtx_instance),
+                            (size_t)f->sphere_count * sizeof(rtx_sphere), (size_t)f->plane_count * sizeof(rtx_plane), (size_t)f->point_light_count * sizeof(rtx_point_light),
+                            (size_t)f->spot_light_count * sizeof(rtx_spot_light), (size_t)f->directional_light_count * sizeof(rtx_directional_light) };
+    size_t off[9], total = 0;
+    for (int k = 0; k < 9; k++) { off[k] = total; total += (len[k] + 255) & ~(size_t)255; if (len[k] == 0) total += 256; }
+    int rc = RTX_OK;
+    if (total > c->d_frame.cap) {                           // growth (first frame, or more instances than ever before): the one case that waits
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        rc = ensure(c, c->d_frame, total + total / 2);
+        if (rc) return rc;
+    }
+    rtx_ctx::FrameStage & st = c->stage[c->stage_next]; c->stage_next = (c->stage_next + 1) % 3;
+    if (st.pending) { HIP_OK(c, hipEventSynchronize(st.done)); st.pending = false; }      // two frames back: long finished in steady state
+    if (total > st.cap) {
+        if (st.host) hipHostFree(st.host);
+        st.host = nullptr; st.cap = 0;
+        HIP_OK(c, hipHostMalloc(&st.host, total + total / 2, hipHostMallocDefault)); st.cap = total + total / 2;
+    }
+    if (!st.done) HIP_OK(c, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    for (int k = 0; k < 9; k++) if (len[k]) memcpy((char *)st.host + off[k], src[k], len[k]);
+    HIP_OK(c, hipMemcpyAsync(c->d_frame.p, st.host, total, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(c, hipEventRecord(st.done, c->stream)); st.pending = true;
+    char * const fb = (char *)c->d_frame.p;
     if (rc) return rc;
 
     DevScene & s = c->scene;
@@ -373,14 +397,14 @@ extern "C" int rtx_set_frame(rtx_ctx * c, const rtx_frame * f) {
     s.textures = (const DevTexture *)c->d_textures.p; s.texture_count = (int)c->h_tex.size();
     s.sky = (const float *)c->d_sky.p; s.sky_size = c->sky_size;
     s.ewa_table = (const float *)c->d_ewa.p;
-    s.tlas_nodes = (const float4 *)c->f_tlas.p; s.tlas_node_count = f->tlas_node_count; s.pk_tlas_nodes = (const float4 *)c->f_tlas_pk.p;
-    s.tlas_indices = (const int32_t *)c->f_tlas_idx.p; s.tlas_index_count = f->tlas_index_count;
-    s.instances = (const rtx_instance *)c->f_inst.p; s.instance_count = f->instance_count;
-    s.spheres = (const rtx_sphere *)c->f_sph.p; s.sphere_count = f->sphere_count;
-    s.planes = (const rtx_plane *)c->f_pln.p; s.plane_count = f->plane_count;
-    s.point_lights = (const rtx_point_light *)c->f_pl.p; s.point_light_count = f->point_light_count;
-    s.spot_lights = (const rtx_spot_light *)c->f_sl.p; s.spot_light_count = f->spot_light_count;
-    s.dir_lights = (const rtx_directional_light *)c->f_dl.p; s.dir_light_count = f->directional_light_count;
+    s.tlas_nodes = (const float4 *)(fb + off[0]); s.tlas_node_count = f->tlas_node_count; s.pk_tlas_nodes = (const float4 *)(fb + off[1]);
+    s.tlas_indices = (const int32_t *)(fb + off[2]); s.tlas_index_count = f->tlas_index_count;
+    s.instances = (const rtx_instance *)(fb + off[3]); s.instance_count = f->instance_count;
+    s.spheres = (const rtx_sphere *)(fb + off[4]); s.sphere_count = f->sphere_count;
+    s.planes = (const rtx_plane *)(fb + off[5]); s.plane_count = f->plane_count;
+    s.point_lights = (const rtx_point_light *)(fb + off[6]); s.point_light_count = f->point_light_count;
+    s.spot_lights = (const rtx_spot_light *)(fb + off[7]); s.spot_light_count = f->spot_light_count;
+    s.dir_lights = (const rtx_directional_light *)(fb + off[8]); s.dir_light_count = f->directional_light_count;
     s.light_count = f->point_light_count + f->spot_light_count + f->directional_light_count;
     c->frame_primitive_materials.clear();
     for (int i = 0; i < f->sphere_count; i++) c->frame_primitive_materials.push_back(f->spheres[i].material_id);

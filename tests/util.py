@@ -67,3 +67,20 @@ def bit_exact(a, b):
     """fp32 arrays equal bit for bit; two NaNs count as equal whatever their sign / payload (x86 and gfx950 generate different default NaNs)."""
     a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
     return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def load_fullsize_golden(name):
+    """8 192 seeded pixels + stats + channel sums of a 1920x1080 frame rendered by the REAL reference
+    (oracle/ref_harness/make_fullsize_goldens.py): atrium_1080p, tori16_1080p_f1..f3."""
+    return dict(np.load(os.path.join(GOLDEN, "fullsize", name + ".npz")))
+
+
+def compare_to_fullsize_golden(out, g):
+    """Bit-exact on the sampled pixels, exact on the ray counts, exact on the whole-frame channel sums (float64 sums of fp32 values: equal
+    iff the multiset of pixel values is — a checksum over all 2 073 600 pixels)."""
+    rgb = out["rgb"][g["ys"], g["xs"]]
+    sums = out["rgb"].astype(np.float64).sum(axis=(0, 1))
+    return {"samples_bit_exact": bit_exact(rgb, g["rgb"]), "max_abs": float(np.nanmax(np.abs(rgb.astype(np.float64) - g["rgb"].astype(np.float64)))),
+            "packed_equal": bool(np.array_equal(out["packed"][g["ys"], g["xs"]], g["packed"])),
+            "stats_equal": [int(out["stats"][k]) for k in ("primary", "shadow", "reflection", "refraction")] == g["stats"].tolist(),
+            "channel_sums_equal": bool(np.array_equal(sums, g["channel_sums"]))}
