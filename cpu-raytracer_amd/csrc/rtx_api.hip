@@ -65,7 +65,7 @@ struct rtx_ctx {
     DevQueues q;
     DevBuf qb[20];
     size_t slots_alloc = 0, shadow_alloc = 0;
-    DevBuf d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma, d_pk_heads;
+    DevBuf d_pk_fifo, d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma, d_pk_heads;
     int trace_blocks_closest = 0, trace_blocks_any = 0, trace_blocks_count = 0;
     int pk_blocks_closest = 0, pk_blocks_any = 0;    // persistent grids of the packet kernels (even: waves % 8 == 0, see k_begin_batch)
     bool merge_any = true;               // one-stream mode: ONE shadow-ray launch for all levels after the last shade (RTX_SERIAL_MERGE_ANY=0: one per level)
@@ -198,9 +198,11 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     if (c->pk_blocks_any > max_blocks) max_blocks = c->pk_blocks_any;       // the packet kernels' per-lane phase spills there too
     if (c->pk_blocks_closest > max_blocks) max_blocks = c->pk_blocks_closest;
     c->q.pk_defer_t0 = 8; if (const char * e = getenv("RTX_PK_DEFER")) c->q.pk_defer_t0 = atoi(e);
+    c->q.pk_defer_t0_closest = 64; if (const char * e = getenv("RTX_PK_DEFER_CLOSEST")) c->q.pk_defer_t0_closest = atoi(e);
     c->q.pk_defer_grow = 3; if (const char * e = getenv("RTX_PK_GROW")) c->q.pk_defer_grow = atoi(e);
     c->q.spill_threads = max_blocks * RTX_TRACE_BLOCK;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast
+    if (!rc) rc = ensure(c, c->d_pk_fifo, (size_t)c->q.spill_threads * RTX_PK_FIFO * 4);
     if (rc) { rtx_destroy(c); return rc; }
     *out_ctx = c;
     return RTX_OK;
@@ -212,7 +214,7 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto & v : c->blas_allocs) for (void * p : v) hipFree(p);
     for (void * p : c->tex_allocs) if (p) hipFree(p);
-    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->d_frame, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads };
+    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->d_frame, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads, &c->d_pk_fifo };
     for (DevBuf * b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf & b : c->qb) if (b.p) hipFree(b.p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
@@ -483,6 +485,7 @@ static int alloc_queues(rtx_ctx * c, int batch_tiles) {
     c->q.spill = (int32_t *)c->d_spill.p;
     c->q.counters = (DevCounters *)c->d_counters.p;
     c->q.pk_heads = (uint32_t *)c->d_pk_heads.p;
+    c->q.pk_fifo = (int32_t *)c->d_pk_fifo.p;
     c->q.fb_rgb = (float *)(c->ext_rgb ? c->ext_rgb : c->d_fb_rgb.p);
     c->q.fb_packed = (uint32_t *)(c->ext_packed ? c->ext_packed : c->d_fb_packed.p);
     return rc;
@@ -541,7 +544,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
     const bool cull = (flags & RTX_RENDER_CULL_DEAD_SHADOW_RAYS) != 0 && !simple && !count_work;
     bool lane = (flags & RTX_RENDER_LANE_TRACE) != 0;
     for (size_t b = 0; b < c->blas_packet_ok.size(); b++) if (c->h_blas[b].nodes && !c->blas_packet_ok[b]) lane = true;      // limits of the packet kernels' packed entries
-    const bool pk_closest = (flags & RTX_RENDER_PACKET_CLOSEST) != 0;      // closest-hit rays: per-lane kernel by default (see rtx.h)
+    const bool pk_closest = (flags & RTX_RENDER_PACKET_CLOSEST) != 0;      // closest-hit packets walk shared subtrees together (default: lanes turn private at once)
     const bool pstat = (flags & RTX_RENDER_PACKET_STATS) != 0 && !simple && !count_work && !lane;
     c->serial = (flags & RTX_RENDER_SERIAL) != 0;
 
@@ -559,6 +562,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
     for (int done = 0; done < tile_count; done += batch_tiles) {
         const int n = (tile_count - done) < batch_tiles ? (tile_count - done) : batch_tiles;
         DevQueues q = c->q;
+        if (pk_closest) q.pk_defer_t0_closest = q.pk_defer_t0;
         q.first_tile = first_tile + done * tile_stride; q.tile_stride = tile_stride; q.tile_count = n; q.primary_slots = n * 1024;
         q.tm_packed = tile_major; q.tm_base = done * 1024;
         const DevScene sc = c->scene;
@@ -588,7 +592,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
             launch_timed(c, "k_trace_closest", c->stream, [&] {
                 if (count_work)     hipLaunchKernelGGL((k_trace<false, true>),   dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (simple)    hipLaunchKernelGGL((k_trace<false, false>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else if (lane || !(pk_closest || pstat)) hipLaunchKernelGGL((k_trace_fast<false>), dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
+                else if (lane)      hipLaunchKernelGGL((k_trace_fast<false>),    dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
                 else if (pstat)     hipLaunchKernelGGL((k_packet<false, true>),  dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
                 else                hipLaunchKernelGGL((k_packet<false, false>), dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
             });

@@ -110,6 +110,7 @@ RTX_D bool pk_slab(float4 q0, float4 q1, const PkRay & r) {
 #endif
 struct PkWalk {                      // everything a packet walk carries; wave-uniform unless noted
     rtx_cptr tlas, nodes, tris;
+    rtx_gptr lane_nodes, lane_tris;                      // the BLAS being walked in the per-lane kernels' layout (per-lane phases)
     int sp, floor_sp, cur_inst, depth;
     int cur_idx, cur_first, cur_cnt;
     unsigned long long m, alive;
@@ -117,6 +118,8 @@ struct PkWalk {                      // everything a packet walk carries; wave-u
     PkRay ray;                                           // per lane
     bool valid, occluded;                                // per lane
     int best_prim, best_tri; float best_u, best_v;       // per lane (closest-hit)
+    unsigned long long pub;                              // closest-hit hybrid: lanes still walking with the packet (the others turned private)
+    int fifo_n;                                          // per lane: entries on the lane's private work list (closest-hit hybrid)
     int psp;                                             // per lane: entries on the lane's PRIVATE stack (hybrid any-hit walk)
     int pk_steps;                                        // steps of the current packet walk (the deferral threshold grows with it)
     uint32_t err;
@@ -172,10 +175,11 @@ RTX_D void pk_push(PkWalk & W, int a, int b, unsigned long long mask, int idx, i
     "s_and_b64 " MASK ", vcc, %[m]\n\t"
 
 template <bool ANY>
-RTX_D void pk_descend(PkWalk & W, int stack_size, int ordered) {
+RTX_D void pk_descend(PkWalk & W, int stack_size, int ordered, int thr) {
     // "s" operands must really be SGPRs: whatever the compiler did with the wave-uniform state, pin it here
     W.cur_first = rfl(W.cur_first); W.cur_cnt = rfl(W.cur_cnt); W.cur_idx = rfl(W.cur_idx); W.m = rfl64(W.m); W.sp = rfl(W.sp);
-    W.depth = rfl(W.depth); W.err = (uint32_t)rfl((int)W.err); stack_size = rfl(stack_size); ordered = rfl(ordered);
+    W.depth = rfl(W.depth); W.err = (uint32_t)rfl((int)W.err); stack_size = rfl(stack_size); ordered = rfl(ordered); thr = rfl(thr);
+    int steps = rfl(W.pk_steps);
     const unsigned long long posx = __ballot(W.ray.d.x > 0.0f), posy = __ballot(W.ray.d.y > 0.0f), posz = __ballot(W.ray.d.z > 0.0f);
     const float eps = RAY_EPSILON;
     const unsigned long long nodes = rfl64((unsigned long long)W.nodes);
@@ -355,19 +359,25 @@ RTX_D void pk_descend(PkWalk & W, int stack_size, int ordered) {
             "s_cmp_eq_u64 s[88:89], 0\n\t"
             "s_cbranch_scc1 PKC_END_%=\n\t"
             "PKC_CHECK_%=:\n\t"
+            "s_add_i32 %[steps], %[steps], 1\n\t"
+            "s_bcnt1_i32_b64 s90, %[m]\n\t"               // hybrid: a node wanted by few lanes goes back to the caller (lanes turn private)
+            "s_cmp_le_i32 s90, %[thr]\n\t"
+            "s_cbranch_scc1 PKC_END_%=\n\t"
             "s_and_b32 s90, %[cnt], 0x3fffffff\n\t"
             "s_cmp_eq_u32 s90, 0\n\t"
             "s_cbranch_scc1 PKC_TOP_%=\n\t"
             "PKC_END_%=:\n\t"
             : [first] "+&s"(W.cur_first), [cnt] "+&s"(W.cur_cnt), [idx] "+&s"(W.cur_idx), [m] "+&s"(W.m), [sp] "+&s"(W.sp), [depth] "+&s"(W.depth), [err] "+&s"(W.err),
+              [steps] "+&s"(steps),
               [sta] "+&v"(W.st_a), [stb] "+&v"(W.st_b), [stmlo] "+&v"(W.st_mlo), [stmhi] "+&v"(W.st_mhi), [stdf] "+&v"(W.st_df), [stidx] "+&v"(W.st_idx)
             : [nodes] "s"(nodes), [oxy] "v"(W.ray.o_xy), [ozz] "v"(W.ray.o_zz), [ixy] "v"(W.ray.i_xy), [izz] "v"(W.ray.i_zz), [tcur] "v"(W.ray.tcur),
-              [posx] "s"(posx), [posy] "s"(posy), [posz] "s"(posz), [ssz] "s"(stack_size), [eps] "s"(eps), [ordered] "s"(ordered)
+              [posx] "s"(posx), [posy] "s"(posy), [posz] "s"(posz), [ssz] "s"(stack_size), [eps] "s"(eps), [ordered] "s"(ordered), [thr] "s"(thr)
             : "vcc", "scc", "m0",
               "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
               "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
               "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
     }
+    W.pk_steps = steps;
 }
 
 // ---- the whole any-hit walk of one BLAS, hand-scheduled ------------------------------------------------------------------------
@@ -607,7 +617,7 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
     if (maxd + 2 > stack_size || err) W.err = 1;       // reference stack: `depth` pending + 2 pushed at the deepest inner node expanded
 }
 
-struct PkHybrid { int * stk; uint32_t lane_lds; int * spill; int spill_stride; int t0, grow; };
+struct PkHybrid { int * stk; float * stk_key; uint32_t lane_lds; int * spill; float * spill_key; int spill_stride; int * fifo; int fifo_stride; int t0, grow; };
 
 // ---- hybrid any-hit walk, per-lane phase -----------------------------------------------------------------------------------------
 // Walks the subtrees the packet walk handed to the lanes' private stacks (entries are nodes that already passed the lane's slab test,
@@ -679,6 +689,101 @@ RTX_D void pk_lane_phase_any(PkWalk & W, const int lane, int * const stk, int * 
     W.psp = 0;
 }
 
+// ---- hybrid closest-hit walk, per-lane phase ----------------------------------------------------------------------------------
+// A lane whose rays no longer agree with its packet turns PRIVATE: from then on every node the packet walk would have handed it (the
+// node at which it left, then every shared stack entry carrying its bit, in the order they are popped = the lane's own visiting order)
+// is appended to the lane's work list instead, and the lane takes no further part in the packet.  Here each lane walks its list front
+// to back, every entry's subtree depth-first with its own stack — BottomLevelBVH::trace (BottomLevelBVH.cpp:355-396) for that ray from
+// that point on: the far child re-tested at pop time against the then-current closest distance (entries not tested yet: the same test
+// on the node's own box), the lane's own near / far order, strict comparisons.  Results are those of the reference's per-ray loop.
+#define RTX_PK_FIFO 48                      // work-list entries per lane (HBM, [entry][thread]); a lane turns private only if the list cannot overflow
+#define PK_FIFO_PRETESTED 0x40000000
+RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered, const PkHybrid & H, rtx_gptr nodes, rtx_gptr tris) {
+    const int fifo_n = W.fifo_n;
+    int fi = 0, sp = 0;
+    const v3 co = V3(W.ray.o_xy.x, W.ray.o_xy.y, W.ray.o_zz.x), cd = W.ray.d, cinv = V3(W.ray.i_xy.x, W.ray.i_xy.y, W.ray.i_zz.x);
+    float tcur = W.ray.tcur;
+    bool have_cur = false; int cur_first = 0, cur_cnt = 0;
+    auto push = [&](int e, float key) {
+        if (sp < RTX_LDS_STACK) { H.stk[sp * RTX_WAVE] = e; H.stk_key[sp * RTX_WAVE] = key; }
+        else if (sp < RTX_MAX_STACK) { H.spill[(sp - RTX_LDS_STACK) * H.spill_stride] = e; H.spill_key[(sp - RTX_LDS_STACK) * H.spill_stride] = key; }
+        else { W.err = 1; return; }
+        sp++;
+    };
+    for (;;) {
+        if (__ballot(have_cur || sp > 0 || fi < fifo_n) == 0ull) break;
+        // inner node: child-pair gather, both slab tests, the lane's own near / far order (BVHNode.h:30-40)
+        if (have_cur && (cur_cnt & 0x3fffffff) == 0) {
+            const int left = cur_first;
+            const float4 la = gld(nodes, 2 * left), lb = gld(nodes, 2 * left + 1), ra = gld(nodes, 2 * left + 2), rb = gld(nodes, 2 * left + 3);
+            float kl = 0.0f, kr = 0.0f;
+            const bool pl = slab_test_sel<true>(la, lb, co, cinv, tcur, kl), pr = slab_test_sel<true>(ra, rb, co, cinv, tcur, kr);
+            bool left_first = true;
+            if (ordered) {
+                const int axis = (int)((uint32_t)cur_cnt >> 30);
+                if (axis == 1) left_first = cd.x > 0.0f; else if (axis == 2) left_first = cd.y > 0.0f; else if (axis == 3) left_first = cd.z > 0.0f;
+            }
+            const bool p_near = left_first ? pl : pr, p_far = left_first ? pr : pl;
+            const int near_first = left_first ? as_i(la.w) : as_i(ra.w), near_cnt = left_first ? as_i(lb.w) : as_i(rb.w);
+            const int far_first  = left_first ? as_i(ra.w) : as_i(la.w), far_cnt  = left_first ? as_i(rb.w) : as_i(lb.w);
+            if (p_near) {
+                if (p_far) {
+                    const int far_leaf = far_cnt & 0x3fffffff;
+                    const float far_key = left_first ? kr : kl;
+                    if ((uint32_t)far_first < (1u << 24) && far_leaf < 16)
+                        push((int)(0x40000000u | (((uint32_t)far_cnt >> 30) << 28) | ((uint32_t)far_leaf << 24) | (uint32_t)far_first), far_key);
+                    else push(left_first ? left + 1 : left, far_key);
+                }
+                cur_first = near_first; cur_cnt = near_cnt;
+            } else if (p_far) { cur_first = far_first; cur_cnt = far_cnt; }
+            else have_cur = false;
+        }
+        // leaf: triangle_trace, BottomLevelBVH.cpp:214-309 (hit test; the accept branch is rebuilt by k_shade)
+        if (have_cur && (cur_cnt & 0x3fffffff) > 0) {
+            have_cur = false;
+            const int cnt = cur_cnt & 0x3fffffff;
+            for (int i = cur_first; i < cur_first + cnt; i++) {
+                const float4 p0 = gld(tris, RTX_TRI_STRIDE * i), e1 = gld(tris, RTX_TRI_STRIDE * i + 1), e2 = gld(tris, RTX_TRI_STRIDE * i + 2);
+                const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
+                const v3 h = vcross(cd, edge_2);
+                const float a = vdot(edge_1, h);
+                const float f = 1.0f / a;
+                const v3 s = vsub(co, V3(p0.x, p0.y, p0.z));
+                const float u = f * vdot(s, h);
+                if (!((u > 0.0f) & (u < 1.0f))) continue;
+                const v3 qq = vcross(s, edge_1);
+                const float v = f * vdot(cd, qq);
+                if (!((v > 0.0f) & ((u + v) < 1.0f))) continue;
+                const float t = f * vdot(edge_2, qq);
+                if (!((t > RAY_EPSILON) & (t < tcur))) continue;
+                tcur = t; W.best_u = u; W.best_v = v; W.best_tri = i; W.best_prim = PRIM_TRI | W.cur_inst;
+            }
+        }
+        // pop: the lane's own stack first, then the next entry of its work list
+        if (!have_cur) {
+            if (sp > 0) {
+                sp--;
+                float key; int e;
+                if (sp < RTX_LDS_STACK) { e = H.stk[sp * RTX_WAVE]; key = H.stk_key[sp * RTX_WAVE]; }
+                else { e = H.spill[(sp - RTX_LDS_STACK) * H.spill_stride]; key = H.spill_key[(sp - RTX_LDS_STACK) * H.spill_stride]; }
+                if (key < tcur) {                       // the reference's pop-time test (slab_test_key: t_near < closest distance now)
+                    if (e & 0x40000000) { cur_first = e & 0x00ffffff; cur_cnt = (int)((((uint32_t)e >> 28) & 3u) << 30) | ((e >> 24) & 15); }
+                    else { const float4 na = gld(nodes, 2 * e), nb = gld(nodes, 2 * e + 1); cur_first = as_i(na.w); cur_cnt = as_i(nb.w); }
+                    have_cur = true;
+                }
+            } else if (fi < fifo_n) {
+                const int e = H.fifo[fi * H.fifo_stride]; fi++;
+                const int idx = e & 0x3fffffff;
+                const float4 na = gld(nodes, 2 * idx), nb = gld(nodes, 2 * idx + 1);
+                float k;
+                if ((e & PK_FIFO_PRETESTED) || slab_test_sel<true>(na, nb, co, cinv, tcur, k)) { cur_first = as_i(na.w); cur_cnt = as_i(nb.w); have_cur = true; }
+            }
+        }
+    }
+    W.ray.tcur = tcur;
+    W.fifo_n = 0;
+}
+
 // Walks until the packet is finished (returns true) or, FAST only, until an instance is entered in which some lane's inverse
 // direction is not finite (returns false: the caller continues with the reference-form variant; the state is consistent).
 // `world(o, d)` reloads a lane's world-space ray (kept in memory, not in registers).
@@ -686,6 +791,17 @@ template <bool ANY, bool PSTAT, bool FAST, bool ASM, typename WorldFn>
 RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool ordered, const PkHybrid & H, WorldFn && world) {
     for (;;) {
         if (W.m != 0ull) {
+            if (!ANY && ASM && FAST && W.floor_sp >= 0) {
+                // closest-hit hybrid: a node wanted by few lanes (threshold grows with the length of the walk) is not walked by the packet;
+                // its lanes turn private and take the node (which they have just passed) as the first entry of their work lists
+                const int thr = H.t0 + (W.pk_steps >> H.grow);
+                if (__popcll(W.m) <= thr && (W.sp - W.floor_sp) + 2 <= RTX_PK_FIFO) {
+                    if ((W.m >> lane) & 1ull) { H.fifo[W.fifo_n * H.fifo_stride] = W.cur_idx | PK_FIFO_PRETESTED; W.fifo_n++; }
+                    W.pub &= ~W.m; W.m = 0ull;
+                    continue;
+                }
+                W.pk_steps++;
+            }
             const int leafc = W.cur_cnt & 0x3fffffff;
             if (leafc > 0) {
                 PK_T0();
@@ -721,7 +837,7 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
                 PK_T1(2);
             } else if (ASM && FAST) {
                 PK_T0();
-                pk_descend<ANY>(W, sc.stack_size, ordered ? 1 : 0);      // inner nodes, hand-scheduled: down to a leaf (or m == 0)
+                pk_descend<ANY>(W, sc.stack_size, ordered ? 1 : 0, (!ANY && W.floor_sp >= 0) ? H.t0 + (W.pk_steps >> H.grow) : -1);      // inner nodes, hand-scheduled: down to a leaf (or m == 0, or too few lanes)
                 PK_T1(1);
             } else {
                 // inner node.  Reference stack: `depth` pending entries, two pushed before one is popped (BottomLevelBVH.cpp:381-387)
@@ -763,6 +879,10 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
         PK_T0();
         if (ANY && W.alive == 0ull) return true;
         if (W.floor_sp >= 0 && W.sp == W.floor_sp) {            // BottomLevelBVH::trace / intersect returned: back to world space
+            if (!ANY && ASM && FAST && W.pub != W.alive) {       // closest-hit hybrid: the private lanes finish this instance on their own
+                pk_lane_phase_closest(W, lane, ordered, H, W.lane_nodes, W.lane_tris);
+                W.pub = W.alive;
+            }
             W.floor_sp = -1; W.nodes = W.tlas;
             v3 o, d; world(o, d);
             pk_set_ray(W.ray, o, d, vrcp(d));                   // finite for every lane of a packet that started FAST
@@ -773,7 +893,14 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
         const int edf = __builtin_amdgcn_readlane(W.st_df, W.sp);
         const unsigned long long em = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(W.st_mhi, W.sp) << 32) |
                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(W.st_mlo, W.sp);
-        const unsigned long long pm = em & W.alive;
+        unsigned long long pm = em & W.alive;
+        if (!ANY && ASM && FAST && (pm & ~W.pub) != 0ull) {
+            // private lanes: the entry goes to their work lists (to be re-tested at its turn unless it is a pretested split entry)
+            if (((pm & ~W.pub) >> lane) & 1ull) {
+                H.fifo[W.fifo_n * H.fifo_stride] = __builtin_amdgcn_readlane(W.st_idx, W.sp) | ((edf & PK_FLAG_PRETESTED) ? PK_FIFO_PRETESTED : 0); W.fifo_n++;
+            }
+            pm &= W.pub;
+        }
         if (pm == 0ull) continue;
         if (edf & PK_FLAG_ITER) {
             if (eb > 1) pk_push<ANY>(W, ea + 1, eb - 1, pm, 0, PK_FLAG_ITER);
@@ -785,6 +912,7 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
             pk_set_ray(W.ray, co, cd, cinv);
             const DevBlas & B = sc.blas[rfl(I.blas_id)];
             W.nodes = pk_cptr(B.pk_nodes); W.tris = pk_cptr(B.tri_hot); W.cur_inst = inst;
+            W.lane_nodes = RTX_GPTR(B.nodes); W.lane_tris = RTX_GPTR(B.tri_hot);
             W.floor_sp = W.sp; W.depth = 0;
             const float4 na = sld(W.nodes, 0), nb = sld(W.nodes, 1);            // BLAS root (BottomLevelBVH.cpp:360-370)
             const bool risky = FAST && __ballot(W.valid && !inv_is_finite(cinv)) != 0ull;
@@ -818,14 +946,21 @@ template <bool ANY, bool PSTAT>
 __global__ __launch_bounds__(RTX_PK_BLOCK, ANY ? RTX_PK_WAVES_ANY : RTX_PK_WAVES_CLOSEST)
 void k_packet(const DevScene sc, const DevQueues q, const int level, const int level_hi) {
     // hybrid any-hit walk: the lanes' private stacks, striped through LDS ([entry][lane]: conflict-free)
-    __shared__ int s_priv[ANY ? RTX_PK_BLOCK / RTX_WAVE : 1][ANY ? RTX_PK_PRIV : 1][RTX_WAVE];
+    // closest-hit: RTX_LDS_STACK entries + their pop-time keys (the per-lane kernels' stack layout, rtx_trace.h)
+    __shared__ int s_priv[RTX_PK_BLOCK / RTX_WAVE][ANY ? RTX_PK_PRIV : 2 * RTX_LDS_STACK][RTX_WAVE];
     const int lane = threadIdx.x & 63;
     PkHybrid H;
-    H.stk = &s_priv[ANY ? (threadIdx.x >> 6) : 0][0][lane];
+    H.stk = &s_priv[threadIdx.x >> 6][0][lane];
+    H.stk_key = (float *)&s_priv[threadIdx.x >> 6][ANY ? 0 : RTX_LDS_STACK][lane];
     H.lane_lds = (uint32_t)(uintptr_t)H.stk;
     H.spill_stride = q.spill_threads;
-    H.spill = q.spill + 2 * (size_t)q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) + (blockIdx.x * blockDim.x + threadIdx.x);
-    H.t0 = q.pk_defer_t0; H.grow = q.pk_defer_grow;
+    {   // spill regions of rtx_trace.h: [0, S) closest entries, [S, 2S) closest keys, [2S, 3S) shadow-ray entries
+        const size_t region = (size_t)q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK), gt = blockIdx.x * blockDim.x + threadIdx.x;
+        H.spill = q.spill + (ANY ? 2 * region : 0) + gt;
+        H.spill_key = (float *)(q.spill + region) + gt;
+        H.fifo = q.pk_fifo + gt; H.fifo_stride = q.spill_threads;
+    }
+    H.t0 = ANY ? q.pk_defer_t0 : q.pk_defer_t0_closest; H.grow = q.pk_defer_grow;
     const uint32_t gwave  = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
     const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE);
 
@@ -929,9 +1064,10 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
                 if ((t > RAY_EPSILON) & (t < W.ray.tcur)) { if (ANY) { W.occluded = true; break; } else { W.ray.tcur = t; W.best_prim = PRIM_PLANE | i; } }
             }
         }
-        W.psp = 0; W.pk_steps = 0;
+        W.psp = 0; W.pk_steps = 0; W.fifo_n = 0;
         W.alive = __ballot(W.valid && !W.occluded);     // any-hit: lanes leave when occluded; closest-hit: constant
         const unsigned long long alive0 = W.alive;
+        W.pub = W.alive;
         if (PSTAT) st_packets++;
 
         if (W.alive != 0ull && sc.tlas_node_count > 0) {

@@ -258,14 +258,14 @@ enum {
                                           launch for all levels, then resolve.  Use when several contexts render consecutive
                                           frames concurrently (one stream each); the default (two streams, shadow rays of level 0
                                           overlapping the deeper levels) gives the lowest latency for one frame at a time          */
-    RTX_RENDER_LANE_TRACE = 16,        /* A/B: per-lane traversal kernel (one ray per lane, divergent 64-byte child-pair gathers: csrc/rtx_trace.h
-                                          k_trace_fast) for shadow rays too, instead of the hybrid wave-packet kernel (csrc/rtx_packet.h) that
-                                          traces them by default.  Frames are bit-identical.                                                 */
-    RTX_RENDER_PACKET_CLOSEST = 64,    /* A/B: closest-hit rays through the wave-packet kernel as well (default: per-lane kernel; a packet of
-                                          incoherent closest-hit rays must keep every lane's own visiting order and cannot hand subtrees to
-                                          per-lane walks the way shadow-ray packets do).  Frames are bit-identical.                          */
+    RTX_RENDER_LANE_TRACE = 16,        /* A/B: round 1's per-lane traversal kernels (persistent threads with lane refill, csrc/rtx_trace.h
+                                          k_trace_fast) instead of the hybrid wave-packet kernels (csrc/rtx_packet.h).  Frames are bit-identical. */
     RTX_RENDER_PACKET_STATS = 32,      /* instrumented packet kernels: rtx_work_counters::reserved[0..4] = packets walked, child-pair steps,
-                                          triangle steps, and the lane occupancy sums of both (what the roofline accounting of bench.py uses) */
+                                          triangle steps, and the lane occupancy sums of both                                                 */
+    RTX_RENDER_PACKET_CLOSEST = 64,    /* A/B: closest-hit packets walk the shared top of the tree together too (same threshold as shadow-ray packets);
+                                          by default every lane of a closest-hit packet walks its own ray from the BLAS root (private stacks in
+                                          LDS), which is faster until the shared part of that walk is hand-scheduled like the shadow-ray
+                                          kernel's.  Frames are bit-identical either way.                                                   */
     RTX_RENDER_CULL_DEAD_SHADOW_RAYS = 4 /* count, but do not traverse, shadow rays whose unshadowed light contribution is exactly 0
                                           (N.L <= 0 or outside a spot cone): the pixel cannot depend on them.  Frames and
                                           rtx_stats are bit-identical with and without this flag.                                   */

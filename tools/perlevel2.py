@@ -6,9 +6,7 @@ from pyrtx import api, host
 os.environ["RTX_SERIAL_MERGE_ANY"] = "0"
 sc = host.atrium_scene(1920, 1080, 3)
 r = api.Renderer(sc)
-st = r.render(packet_stats=True, serial=True)
-print({k: v for k, v in st["work"].items() if k.startswith("pk_")}, st["stats"])
-for mode in (dict(), dict(lane_trace=True)):
+for mode in (dict(), dict(packet_closest=True), dict(lane_trace=True)):
     for _ in range(3): r.render_async(serial=True, **mode)
     r.synchronize(); r.enable_timing(True)
     N = 10

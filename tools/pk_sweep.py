@@ -7,10 +7,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from pyrtx import api, host
     sc = host.atrium_scene(1920, 1080, 3)
     r = api.Renderer(sc)
-    a = r.render(serial=True); b = r.render(serial=True, lane_trace=True)
+    a = r.render(serial=True, packet_closest=True); b = r.render(serial=True, lane_trace=True)
     same = np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32)) and a["stats"] == b["stats"]
     out = []
-    for mode in (dict(), dict(lane_trace=True)):
+    for mode in (dict(packet_closest=True), dict(lane_trace=True)):
         for _ in range(3): r.render_async(serial=True, **mode)
         r.synchronize(); r.enable_timing(True)
         for _ in range(10): r.render_async(serial=True, **mode)
@@ -18,7 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         g = {}
         for n, ms in kt: g.setdefault(n, []).append(ms)
         out.append({k: round(float(np.sum(v)) / 10, 4) for k, v in g.items()})
-    print("T0=%s grow=%s scale=%s lib=%s parity=%s any=%.4f (lane %.4f)" % (os.environ.get("RTX_PK_DEFER"), os.environ.get("RTX_PK_GROW"), os.environ.get("RTX_PK_GRID_SCALE"), os.path.basename(os.environ.get("RTX_HIP_LIB", "default")), same, out[0]["k_trace_any"], out[1]["k_trace_any"]), flush=True)
+    print("T0=%s grow=%s scale=%s lib=%s parity=%s any=%.4f (lane %.4f) closest=%.4f (lane %.4f)" % (os.environ.get("RTX_PK_DEFER"), os.environ.get("RTX_PK_GROW"), os.environ.get("RTX_PK_GRID_SCALE"), os.path.basename(os.environ.get("RTX_HIP_LIB", "default")), same, out[0]["k_trace_any"], out[1]["k_trace_any"], out[0]["k_trace_closest"], out[1]["k_trace_closest"]), flush=True)
 else:
     # arguments: T0:grow[:gridscale[:libvariant]] ...
     for spec in sys.argv[1:] or ["8:3"]:
