@@ -65,7 +65,7 @@ struct rtx_ctx {
     DevQueues q;
     DevBuf qb[20];
     size_t slots_alloc = 0, shadow_alloc = 0;
-    DevBuf d_pk_fifo, d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma, d_pk_heads;
+    DevBuf d_stats_partial, d_pk_fifo, d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma, d_pk_heads;
     int trace_blocks_closest = 0, trace_blocks_any = 0, trace_blocks_count = 0;
     int pk_blocks_closest = 0, pk_blocks_any = 0;    // persistent grids of the packet kernels (even: waves % 8 == 0, see k_begin_batch)
     bool merge_any = true;               // one-stream mode: ONE shadow-ray launch for all levels after the last shade (RTX_SERIAL_MERGE_ANY=0: one per level)
@@ -214,7 +214,7 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto & v : c->blas_allocs) for (void * p : v) hipFree(p);
     for (void * p : c->tex_allocs) if (p) hipFree(p);
-    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->d_frame, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads, &c->d_pk_fifo };
+    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->d_frame, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads, &c->d_pk_fifo, &c->d_stats_partial };
     for (DevBuf * b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf & b : c->qb) if (b.p) hipFree(b.p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
@@ -314,15 +314,19 @@ extern "C" int rtx_upload_texture(rtx_ctx * c, int32_t texture_id, const rtx_tex
     hipSetDevice(c->cfg.device);
     if ((size_t)texture_id >= c->h_tex.size()) { size_t old = c->h_tex.size(); c->h_tex.resize(texture_id + 1); for (size_t i = old; i < c->h_tex.size(); i++) memset(&c->h_tex[i], 0, sizeof(DevTexture)); }
     void * d = nullptr;
-    HIP_OK(c, hipMalloc(&d, (size_t)texel_count * 12));
+    HIP_OK(c, hipMalloc(&d, (size_t)texel_count * 16));
     if (c->h_tex[texture_id].texels) {            // re-upload of an id: the old texel array is released (after the frames that may still read it)
         HIP_OK(c, hipStreamSynchronize(c->stream));
         for (void *& p : c->tex_allocs) if (p == (void *)c->h_tex[texture_id].texels) { hipFree(p); p = nullptr; }
     }
     c->tex_allocs.push_back(d);
-    HIP_OK(c, hipMemcpy(d, texels_rgb, (size_t)texel_count * 12, hipMemcpyHostToDevice));
+    {   // float3 texels of the ABI -> one float4 per texel on the device
+        std::vector<float4> padded((size_t)texel_count);
+        for (int64_t i = 0; i < texel_count; i++) padded[(size_t)i] = make_float4(texels_rgb[3 * i], texels_rgb[3 * i + 1], texels_rgb[3 * i + 2], 0.0f);
+        HIP_OK(c, hipMemcpy(d, padded.data(), (size_t)texel_count * 16, hipMemcpyHostToDevice));
+    }
     c->h_tex[texture_id].desc = *desc;
-    c->h_tex[texture_id].texels = (const float *)d;
+    c->h_tex[texture_id].texels = (const float4 *)d;
     c->refs_dirty = true;
     return upload(c, c->d_textures, c->h_tex.data(), c->h_tex.size() * sizeof(DevTexture));
 }
@@ -557,7 +561,10 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
     if (rc) return rc;
     const int levels = c->cfg.bounces + 1;
     const int stream_blocks = c->n_cu * 8;          // k_resolve (256 threads)
-    const int shade_blocks = c->n_cu * 4;           // k_shade (RTX_SHADE_BLOCK = 384 threads, 2 resident blocks per CU)
+    int shade_blocks = c->n_cu * 4;                 // k_shade (RTX_SHADE_BLOCK = 384 threads, 2 resident blocks per CU)
+    if (const char * e = getenv("RTX_SHADE_GRID")) shade_blocks = c->n_cu * atoi(e);
+    rc = ensure(c, c->d_stats_partial, (size_t)(RTX_MAX_LEVELS + 1) * shade_blocks * 4 * sizeof(uint32_t));
+    if (rc) return rc;
 
     for (int done = 0; done < tile_count; done += batch_tiles) {
         const int n = (tile_count - done) < batch_tiles ? (tile_count - done) : batch_tiles;
@@ -565,6 +572,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         if (pk_closest) q.pk_defer_t0_closest = q.pk_defer_t0;
         q.first_tile = first_tile + done * tile_stride; q.tile_stride = tile_stride; q.tile_count = n; q.primary_slots = n * 1024;
         q.tm_packed = tile_major; q.tm_base = done * 1024;
+        q.stats_partial = (uint32_t *)c->d_stats_partial.p; q.shade_blocks = shade_blocks;
         const DevScene sc = c->scene;
         const bool plain = count_work || simple || sc.heatmap;
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, q.counters, q.pk_heads, (uint32_t)q.primary_slots,

@@ -9,6 +9,13 @@
 #include <stdint.h>
 #include "../../include/rtx.h"
 
+// Per-lane pointers to BVH nodes / triangles / texels come out of device tables, so the compiler cannot prove their address space and
+// would emit FLAT loads (LDS-aperture check, lgkmcnt + vmcnt).  They always point into HBM: say so (global_load_dwordx4).
+typedef float rtx_f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) rtx_f4v * rtx_gptr;
+#define RTX_GPTR(p) ((rtx_gptr)(const void *)(p))
+static __device__ __forceinline__ float4 gld(rtx_gptr p, int i) { const rtx_f4v v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+
 #define RTX_MAX_LEVELS   12          // NUMBER_OF_BOUNCES + 1 wavefront levels supported
 #ifndef RTX_LDS_STACK
 #define RTX_TRI_STRIDE   4           // float4 per hot triangle on the device: p0, e1, e2 + padding = one 64-byte line per triangle
@@ -43,7 +50,7 @@ struct DevBlas {
 
 struct DevTexture {
     rtx_texture_desc desc;
-    const float *    texels;              // float3 per texel
+    const float4 *   texels;              // ONE float4 per texel (rgb, 0): a texel is a single 16-byte load (rtx_texture.h)
 };
 
 struct DevCounters {
@@ -129,6 +136,8 @@ struct DevQueues {
     int32_t       pk_defer_t0_closest;   // the same threshold for closest-hit packets (64 = every lane walks its ray privately from the BLAS root)
     int32_t       pk_defer_t0;    // hybrid any-hit walk: nodes wanted by at most this many lanes (+ walk length / 8) go to the lanes' private stacks
     DevCounters * counters;
+    uint32_t *    stats_partial;  // [level][k_shade block][4]: per-block ray tallies, summed by k_resolve(level 0) (no atomics at the end of k_shade)
+    int32_t       shade_blocks;
     uint32_t *    pk_heads;       // packet-queue heads of the packet kernels: [closest | any][level][8 heads], 128 bytes apart (rtx_packet.h)
     uint32_t *    tm_packed;      // group rendering: level-0 pixels go, packed, to tm_packed[tm_base + primary slot] (tile-major) instead of the raster framebuffer
     int32_t       tm_base;

@@ -969,7 +969,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
     // packets: closest-hit = consecutive 64-slot groups of the level's queue; any-hit = per (level, light) segment, each padded
     // to whole packets so that a packet never mixes lights or levels
     uint32_t npk = 0;
-    if (ANY) { for (int d = level; d <= level_hi; d++) npk += ((ctr->lit_count[d] + 63u) >> 6) * (uint32_t)nL; }
+    if (ANY) { for (int d = level; d <= level_hi; d++) npk += ((shadow_slots(ctr, q, d) + 63u) >> 6) * (uint32_t)nL; }
     else npk = (ctr->ray_count[level] + 63u) >> 6;
     npk = (uint32_t)rfl((int)npk);
     uint32_t * const heads = q.pk_heads + (size_t)((ANY ? RTX_MAX_LEVELS + 1 : 0) + level) * RTX_PK_CLASSES * 32;
@@ -1019,10 +1019,10 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
         uint32_t pix_idx = 0;
         if (ANY) {
             uint32_t local = pk; int d = level;
-            uint32_t lit_n = ctr->lit_count[d], seg = (lit_n + 63u) >> 6;
-            while (d < level_hi && local >= seg * (uint32_t)nL) { local -= seg * (uint32_t)nL; d++; lit_n = ctr->lit_count[d]; seg = (lit_n + 63u) >> 6; }
+            uint32_t lit_n = shadow_slots(ctr, q, d), seg = (lit_n + 63u) >> 6;
+            while (d < level_hi && local >= seg * (uint32_t)nL) { local -= seg * (uint32_t)nL; d++; lit_n = shadow_slots(ctr, q, d); seg = (lit_n + 63u) >> 6; }
             const uint32_t light = local / seg, rank = (local - light * seg) * 64u + (uint32_t)lane;
-            W.valid = rank < lit_n;
+            W.valid = rank < lit_n && shadow_slot_is_lit(q, d, rank);      // the shadow rays of the 64 rays of the level's packet `local % seg`
             if (W.valid) {
                 out_slot = (uint32_t)q.shadow_base[d] + light * (uint32_t)q.level_cap[d] + rank;
                 const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot];

@@ -189,6 +189,23 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
         __syncthreads();                          // s_wave_cnt / s_block_base are reused by the next allocation
         return r;
     };
+    // two kinds of slots from ONE allocation: per block [all `a` slots in lane order][all `b` slots in lane order]
+    auto block_alloc2 = [&](bool want_a, bool want_b, uint32_t * counter, uint32_t & slot_a, uint32_t & slot_b) {
+        const unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
+        if (lane == 0) s_wave_cnt[wave_in_block] = (uint32_t)__popcll(ma) | ((uint32_t)__popcll(mb) << 16);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < RTX_SHADE_BLOCK / 64; w++) tot += (s_wave_cnt[w] & 0xffffu) + (s_wave_cnt[w] >> 16);
+            s_block_base = tot ? atomicAdd(counter, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t off_a = s_block_base, tot_a = 0, off_b = 0;
+        for (int w = 0; w < RTX_SHADE_BLOCK / 64; w++) { const uint32_t ca = s_wave_cnt[w] & 0xffffu, cb = s_wave_cnt[w] >> 16; if (w < wave_in_block) { off_a += ca; off_b += cb; } tot_a += ca; }
+        slot_a = off_a + (uint32_t)__popcll(ma & ((1ull << lane) - 1ull));
+        slot_b = s_block_base + tot_a + off_b + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+        __syncthreads();                          // s_wave_cnt / s_block_base are reused by the next iteration
+    };
     const int lit_cap = q.level_cap[level];
     // wave-uniform tallies (SGPRs): ballot popcounts instead of one VGPR counter per statistic
     uint32_t n_shadow = 0, n_refl = 0, n_refr = 0, n_primary = 0, n_shaded = 0, n_sky = 0, n_trihit = 0;
@@ -258,13 +275,11 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
             n_shaded += (uint32_t)__popcll(__ballot(is_hit));
             n_trihit += (uint32_t)__popcll(__ballot(is_hit && PRIM_KIND(prim) == PRIM_TRI));
         }
-        // ---- shadow rays: rank allocation for lit hits (ballot + popcount prefix + one atomic) ----
+        // ---- shadow rays: one per light for every lit hit, in the hit's OWN slot of the shadow queue (no compaction: a shadow-ray packet
+        // is then the same 64 rays as the packet that found the hits — the same 8x8 pixels at level 0 — and the kernel spends no atomic
+        // here; the few lanes without a lit hit are skipped by the shadow-ray kernels, which read NF_LIT from the node record) ----
         const bool lit = (flags & NF_LIT) != 0;
-        int lit_rank = -1;
-        {
-            const uint32_t rnk = block_alloc(lit, &ctr->lit_count[level]);
-            if (lit) lit_rank = (int)rnk;
-        }
+        const int lit_rank = (int)idx;
         if (lit) {
             const v3 to_camera = vnormalize(vsub(v3p(sc.cam_pos), h.point));     // Raytracer.cpp:152 (camera, not ray origin)
             int L = 0;
@@ -317,14 +332,36 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
         n_shadow += (uint32_t)nL * (uint32_t)__popcll(__ballot(lit));           // counted before the occlusion test (:163,180,192)
 
         // ---- secondary rays (Raytracer.cpp:204-346) ----
-        // Each kind is computed, wave-compacted (ballot + popcount prefix + one atomicAdd per wave) and written before the
-        // next one is started, so only one child ray is live at a time (register pressure).
+        // Which children exist is decided first (cheap), both kinds get their queue slots from ONE block-wide allocation (one global
+        // atomic per 384 rays: the counter sustains ~90 atomics/us, three per block iteration kept this kernel at that rate), then each
+        // child ray is computed and written, one kind at a time (register pressure).
         float F_r = 0.0f;
         v3 absorption = V3(0, 0, 0);
         const bool deeper = is_hit && bounces_left > 0;
-        auto append_child = [&](bool spawn, const RayFull & cr, uint32_t parent_bits) {
-            const uint32_t ci = block_alloc(spawn, &ctr->ray_count[level + 1]);
-            if (!spawn) return;
+        const bool reflection_mask = deeper && vdot(Ks, Ks) > 0.0f;
+        const bool refraction_mask = deeper && vdot(Kt, Kt) > 0.0f;
+        bool spawn_refr = false, entering = false;
+        float eta = 1.0f, cos_theta = 0.0f, kk = 0.0f, n_1 = 1.0f, n_2 = 1.0f;
+        if (reflection_mask) flags |= NF_REFL;
+        if (refraction_mask) {
+            flags |= NF_REFR;
+            const float dot = vdot(ray.d, h.normal);
+            entering = dot < 0.0f;
+            const float air = 1.0f;
+            n_1 = entering ? air : ior;
+            n_2 = entering ? ior : air;
+            cos_theta = entering ? (0.0f - dot) : dot;
+            eta = n_1 / n_2;
+            kk = 1.0f - (eta * eta * (1.0f - (cos_theta * cos_theta)));
+            if (entering) flags |= NF_ENTER;
+            if (kk < 0.0f) flags |= NF_TIR;                                       // :310-314
+            else spawn_refr = true;
+        }
+        n_refl += (uint32_t)__popcll(__ballot(reflection_mask));
+        n_refr += (uint32_t)__popcll(__ballot(spawn_refr));
+        uint32_t ci_refl, ci_refr;
+        block_alloc2(reflection_mask, spawn_refr, &ctr->ray_count[level + 1], ci_refl, ci_refr);
+        auto write_child = [&](uint32_t ci, const RayFull & cr, uint32_t parent_bits) {
             if (ci >= (uint32_t)q.level_cap[level + 1]) { atomicOr(&ctr->error_flags, ERR_QUEUE_OVERFLOW); return; }
             const uint32_t cs = (uint32_t)q.level_base[level + 1] + ci;
             q.r0[cs] = make_float4(cr.o.x, cr.o.y, cr.o.z, cr.d.x);
@@ -333,68 +370,43 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
             q.r3[cs] = make_float4(cr.dD_dx.x, cr.dD_dx.y, cr.dD_dx.z, cr.dD_dy.x);
             q.r4[cs] = make_float4(cr.dD_dy.y, cr.dD_dy.z, as_f(pixel), as_f((int)parent_bits));
         };
-        {
-            const bool reflection_mask = deeper && vdot(Ks, Ks) > 0.0f;
+        if (reflection_mask) {
             RayFull rr;
-            rr.o = rr.d = rr.dO_dx = rr.dO_dy = rr.dD_dx = rr.dD_dy = V3(0, 0, 0);
-            if (reflection_mask) {
-                flags |= NF_REFL;
-                rr.o = h.point;
-                const float dn = vdot(ray.d, h.normal);
-                rr.d = vsub(ray.d, vmuls(h.normal, 2.0f * dn));                   // Math::reflect, Math.h:28-30
-                rr.dO_dx = h.dO_dx; rr.dO_dy = h.dO_dy;
-                const float dDN_dx = vdot(ray.dD_dx, h.normal) + vdot(ray.d, h.dN_dx);
-                const float dDN_dy = vdot(ray.dD_dy, h.normal) + vdot(ray.d, h.dN_dy);
-                rr.dD_dx = vsub(ray.dD_dx, vmuls(vadd(vmuls(h.dN_dx, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dx)), 2.0f));
-                rr.dD_dy = vsub(ray.dD_dy, vmuls(vadd(vmuls(h.dN_dy, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dy)), 2.0f));
-            }
-            n_refl += (uint32_t)__popcll(__ballot(reflection_mask));
-            append_child(reflection_mask, rr, slot);
+            rr.o = h.point;
+            const float dn = vdot(ray.d, h.normal);
+            rr.d = vsub(ray.d, vmuls(h.normal, 2.0f * dn));                       // Math::reflect, Math.h:28-30
+            rr.dO_dx = h.dO_dx; rr.dO_dy = h.dO_dy;
+            const float dDN_dx = vdot(ray.dD_dx, h.normal) + vdot(ray.d, h.dN_dx);
+            const float dDN_dy = vdot(ray.dD_dy, h.normal) + vdot(ray.d, h.dN_dy);
+            rr.dD_dx = vsub(ray.dD_dx, vmuls(vadd(vmuls(h.dN_dx, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dx)), 2.0f));
+            rr.dD_dy = vsub(ray.dD_dy, vmuls(vadd(vmuls(h.dN_dy, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dy)), 2.0f));
+            write_child(ci_refl, rr, slot);
         }
-        {
-            const bool refraction_mask = deeper && vdot(Kt, Kt) > 0.0f;
-            bool spawn_refr = false;
+        if (spawn_refr) {
             RayFull rf;
-            rf.o = rf.d = rf.dO_dx = rf.dO_dy = rf.dD_dx = rf.dD_dy = V3(0, 0, 0);
-            if (refraction_mask) {
-                flags |= NF_REFR;
-                const float dot = vdot(ray.d, h.normal);
-                const bool entering = dot < 0.0f;
-                const float air = 1.0f;
-                const float n_1 = entering ? air : ior;
-                const float n_2 = entering ? ior : air;
-                float cos_theta = entering ? (0.0f - dot) : dot;
-                const v3 normal = entering ? h.normal : vneg(h.normal);
-                const float eta = n_1 / n_2;
-                const float k = 1.0f - (eta * eta * (1.0f - (cos_theta * cos_theta)));
-                if (entering) flags |= NF_ENTER;
-                if (k < 0.0f) {
-                    flags |= NF_TIR;                                              // :310-314
-                } else {
-                    spawn_refr = true;
-                    rf.o = h.point;
-                    rf.d = vadd(vmuls(ray.d, eta), vmuls(normal, (eta * cos_theta) - sqrtf(k)));   // Math::refract, Math.h:34-36
-                    rf.dO_dx = h.dO_dx; rf.dO_dy = h.dO_dy;
-                    const float dDN_dx = vdot(ray.dD_dx, h.normal) + vdot(ray.d, h.dN_dx);
-                    const float dDN_dy = vdot(ray.dD_dy, h.normal) + vdot(ray.d, h.dN_dy);
-                    const float D_dot_N = -cos_theta;
-                    const float Dprime_dot_N = -sqrtf(k);
-                    const float mu = -(eta * cos_theta + Dprime_dot_N);
-                    rf.dD_dx = vsub(vmuls(ray.dD_dx, eta), vmuls(vadds(vmul(h.dN_dx, h.normal), mu * D_dot_N), dDN_dx));   // :341-342 literally
-                    rf.dD_dy = vsub(vmuls(ray.dD_dy, eta), vmuls(vadds(vmul(h.dN_dy, h.normal), mu * D_dot_N), dDN_dy));
-                    absorption = vsub(Kt, V3(1.0f, 1.0f, 1.0f));                  // :350
-                    float r_0 = (n_1 - n_2) / (n_1 + n_2);                        // Schlick, :378-391
-                    r_0 = r_0 * r_0;
-                    if (n_1 > n_2) cos_theta = 0.0f - vdot(rf.d, normal);
-                    const float omc  = 1.0f - cos_theta;
-                    const float omc2 = omc * omc;
-                    F_r = r_0 + ((1.0f - r_0) * omc2) * (omc2 * omc);
-                }
-            }
-            n_refr += (uint32_t)__popcll(__ballot(spawn_refr));
-            append_child(spawn_refr, rf, slot | 0x80000000u);
+            const v3 normal = entering ? h.normal : vneg(h.normal);
+            rf.o = h.point;
+            rf.d = vadd(vmuls(ray.d, eta), vmuls(normal, (eta * cos_theta) - sqrtf(kk)));      // Math::refract, Math.h:34-36
+            rf.dO_dx = h.dO_dx; rf.dO_dy = h.dO_dy;
+            const float dDN_dx = vdot(ray.dD_dx, h.normal) + vdot(ray.d, h.dN_dx);
+            const float dDN_dy = vdot(ray.dD_dy, h.normal) + vdot(ray.d, h.dN_dy);
+            const float D_dot_N = -cos_theta;
+            const float Dprime_dot_N = -sqrtf(kk);
+            const float mu = -(eta * cos_theta + Dprime_dot_N);
+            rf.dD_dx = vsub(vmuls(ray.dD_dx, eta), vmuls(vadds(vmul(h.dN_dx, h.normal), mu * D_dot_N), dDN_dx));   // :341-342 literally
+            rf.dD_dy = vsub(vmuls(ray.dD_dy, eta), vmuls(vadds(vmul(h.dN_dy, h.normal), mu * D_dot_N), dDN_dy));
+            absorption = vsub(Kt, V3(1.0f, 1.0f, 1.0f));                          // :350
+            float r_0 = (n_1 - n_2) / (n_1 + n_2);                                // Schlick, :378-391
+            r_0 = r_0 * r_0;
+            float ct = cos_theta;
+            if (n_1 > n_2) ct = 0.0f - vdot(rf.d, normal);
+            const float omc  = 1.0f - ct;
+            const float omc2 = omc * omc;
+            F_r = r_0 + ((1.0f - r_0) * omc2) * (omc2 * omc);
+            write_child(ci_refr, rf, slot | 0x80000000u);
         }
 
+        if (!valid && idx < count) q.n0[slot] = make_float4(0.0f, 0.0f, 0.0f, as_f(0));      // clipped pixel of an edge tile: no hit, no shadow rays
         if (valid) {
             q.n0[slot] = make_float4(albedo.x, albedo.y, albedo.z, as_f(flags));
             if (flags & NF_HIT) {
@@ -405,20 +417,31 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
         }
     }
 
-    // statistics: the tallies are already per-wave sums; one atomic per counter per wave
+    // statistics: the tallies are per-wave sums; the block adds them up in LDS and ONE thread hands them on.  (One atomic per wave and
+    // counter was 20 000 atomics on one cache line at the end of every level-0 launch: at the ~90 atomics/us that line sustains, two
+    // thirds of this kernel's time.)  Per-block partial sums go to HBM without any atomic; k_resolve(level 0) adds them into the frame's
+    // PerformanceStats.
     if (COUNT) for (int off = 32; off > 0; off >>= 1) n_texels += __shfl_down(n_texels, off);
+    __shared__ uint32_t s_tally[RTX_SHADE_BLOCK / 64][10];
     if (lane == 0) {
-        if (n_primary) atomicAdd(&ctr->stats[0], (unsigned long long)n_primary);
-        if (n_shadow)  atomicAdd(&ctr->stats[1], (unsigned long long)n_shadow);
-        if (n_refl)    atomicAdd(&ctr->stats[2], (unsigned long long)n_refl);
-        if (n_refr)    atomicAdd(&ctr->stats[3], (unsigned long long)n_refr);
-        if (COUNT) {
-            atomicAdd(&ctr->work[W_SHADED], (unsigned long long)n_shaded);
-            atomicAdd(&ctr->work[W_SKY], (unsigned long long)n_sky);
-            atomicAdd(&ctr->work[W_TEXELS], (unsigned long long)n_texels);
-            atomicAdd(&ctr->work[W_TRI_HITS], (unsigned long long)n_trihit);
-            atomicAdd(&ctr->work[W_SPAWNED], (unsigned long long)(n_refl + n_refr));
+        uint32_t * tw = s_tally[wave_in_block];
+        tw[0] = n_primary; tw[1] = n_shadow; tw[2] = n_refl; tw[3] = n_refr;
+        tw[4] = n_shaded; tw[5] = n_sky; tw[6] = n_texels; tw[7] = n_trihit;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        uint32_t tot = 0;
+        for (int w = 0; w < RTX_SHADE_BLOCK / 64; w++) tot += s_tally[w][threadIdx.x];
+        if (threadIdx.x < 4) q.stats_partial[((size_t)level * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = tot;
+        else if (COUNT && tot) {
+            const int wi[4] = { W_SHADED, W_SKY, W_TEXELS, W_TRI_HITS };
+            atomicAdd(&ctr->work[wi[threadIdx.x - 4]], (unsigned long long)tot);
         }
+    }
+    if (COUNT && threadIdx.x == 0) {
+        uint32_t spawned = 0;
+        for (int w = 0; w < RTX_SHADE_BLOCK / 64; w++) spawned += s_tally[w][2] + s_tally[w][3];
+        if (spawned) atomicAdd(&ctr->work[W_SPAWNED], (unsigned long long)spawned);
     }
 }
 
@@ -453,7 +476,18 @@ void k_heatmap(const DevScene sc, const DevQueues q) {
 
 __global__ __launch_bounds__(256)
 void k_resolve(const DevScene sc, const DevQueues q, const int level) {
-    const DevCounters * const ctr = q.counters;
+    DevCounters * const ctr = q.counters;
+    if (level == 0 && blockIdx.x == 0 && threadIdx.x < 64) {
+        // PerformanceStats of this batch: the per-block partial sums of every level's k_shade launch (WorkerThread.cpp:131-148 sums per thread)
+        const int n = (sc.bounces + 1) * q.shade_blocks;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        for (int i = threadIdx.x; i < n; i += 64) {
+            const uint32_t * p = q.stats_partial + (size_t)i * 4;
+            t0 += p[0]; t1 += p[1]; t2 += p[2]; t3 += p[3];
+        }
+        for (int off = 32; off > 0; off >>= 1) { t0 += __shfl_down(t0, off); t1 += __shfl_down(t1, off); t2 += __shfl_down(t2, off); t3 += __shfl_down(t3, off); }
+        if (threadIdx.x == 0) { atomicAdd(&ctr->stats[0], t0); atomicAdd(&ctr->stats[1], t1); atomicAdd(&ctr->stats[2], t2); atomicAdd(&ctr->stats[3], t3); }
+    }
     uint32_t count = ctr->ray_count[level];
     if (count > (uint32_t)q.level_cap[level]) count = (uint32_t)q.level_cap[level];
     const int nL = sc.light_count;
@@ -472,7 +506,7 @@ void k_resolve(const DevScene sc, const DevQueues q, const int level) {
             const v3 albedo = V3(n0.x, n0.y, n0.z);
             v3 result = V3(0.0f, 0.0f, 0.0f);
             if (flags & NF_LIT) {                                      // :146-200
-                const uint32_t rank = (uint32_t)as_i(n3.x);
+                const uint32_t rank = idx;                          // a hit's shadow rays sit in the hit's own slot of every light's segment
                 v3 diffuse = v3p(sc.ambient);
                 for (int L = 0; L < nL; L++) {
                     const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + rank;

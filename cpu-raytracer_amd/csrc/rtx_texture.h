@@ -1,160 +1,202 @@
-// rtx_texture.h — device-side Texture::sample* and Sky::sample.
-// Follows Texture.h:33-49, Texture.cpp:131-337 and Sky.cpp:28-68 operation by operation.
+// rtx_texture.h — texture and sky look-ups of the shade kernel (the reference's Texture::sample, Texture.h:33-49, and Sky::sample,
+// Sky.cpp:28-68, at SIMD_LANE_SIZE 1).
+//
+// Layout and fetch path (MI355X):
+//   * a texel is ONE float4 in HBM (rgb + padding, converted at rtx_upload_texture): one global_load_dwordx4 per texel instead of
+//     three dword loads, 16-byte aligned so a 2x2 footprint is four independent 16-byte requests;
+//   * a mip level is described once per sample by a TexLevel (base pointer, extent, wrap masks).  Mip chains only exist for
+//     power-of-two textures (Texture.cpp:49-55), so their wrap-around is an AND with (extent - 1) — identical to Math::mod
+//     (Math.h:54-61) for every int, two's complement — instead of two integer divisions per texel; other extents keep the modulo;
+//   * a bilinear footprint wraps each of its two columns / rows once, issues its four loads together and only then blends;
+//     the anisotropic filter fetches the footprints of two taps at a time (eight loads in flight) before it accumulates them.
+//
+// What is pinned by parity and therefore kept exactly: every fp32 operation and its order in the level-of-detail, weight and
+// coordinate arithmetic and in the accumulation of texels (the probes of tests/test_gpu_units.py come from the real reference and a
+// different association flips a mip level or a last bit); float -> int is cvtss2si (Util.h:39-41).
 #pragma once
 #include "rtx_math.h"
 #include "rtx_device.h"
 #include "rtx_libm.h"
 
-struct TexCtx {
-    const DevTexture * t;
-    uint32_t           fetches;    // texel_fetches work counter
+struct TexLevel {                       // one mip level of one texture, as the samplers see it
+    rtx_gptr base;                      // first texel of the level (float4 each)
+    int w, h;
+    int mask_x, mask_y;                 // extent - 1 when the extent is a power of two, else -1 (use the modulo)
+    float wf, hf;
 };
 
-RTX_D v3 fetch_texel(TexCtx & tc, int x, int y, int level) {        // Texture.cpp:131-147
+struct TexCtx {
+    const DevTexture * t;
+    uint32_t           fetches;         // texel_fetches work counter (COUNT builds)
+};
+
+RTX_D TexLevel tex_level(const TexCtx & tc, int level) {
     const rtx_texture_desc & d = tc.t->desc;
-    int offset = d.mip_offsets[level];
-    int lw = d.width >> level, lh = d.height >> level;
-    x = mod_pos(x, lw);
-    y = mod_pos(y, lh);
+    TexLevel L;
+    L.w = d.width >> level; L.h = d.height >> level;
+    L.base = RTX_GPTR(tc.t->texels) + d.mip_offsets[level];
+    L.mask_x = (L.w & (L.w - 1)) == 0 ? L.w - 1 : -1;
+    L.mask_y = (L.h & (L.h - 1)) == 0 ? L.h - 1 : -1;
+    L.wf = (float)L.w; L.hf = (float)L.h;
+    return L;
+}
+RTX_D int tex_wrap(int v, int extent, int mask) { return mask >= 0 ? (v & mask) : mod_pos(v, extent); }      // Math::mod, Texture.cpp:139-140
+RTX_D v3 tex_load(const TexLevel & L, int x, int y) { const float4 c = gld(L.base, x + y * L.w); return V3(c.x, c.y, c.z); }
+
+// Texture::fetch_texel, Texture.cpp:131-147
+RTX_D v3 tex_texel(TexCtx & tc, const TexLevel & L, int x, int y) {
     tc.fetches++;
-    const __attribute__((address_space(1))) float * p = (const __attribute__((address_space(1))) float *)(const void *)tc.t->texels + 3 * (size_t)(offset + x + y * lw);   // texel arrays live in HBM: global_load
-    return V3(p[0], p[1], p[2]);
+    return tex_load(L, tex_wrap(x, L.w, L.mask_x), tex_wrap(y, L.h, L.mask_y));
 }
 
-RTX_D v3 sample_nearest(TexCtx & tc, float s, float t) {            // Texture.cpp:149-154
-    int x = f2i_rn_x86(s * (float)tc.t->desc.width);
-    int y = f2i_rn_x86(t * (float)tc.t->desc.height);
-    return fetch_texel(tc, x, y, 0);
+// A bilinear footprint (Texture::sample_bilinear, Texture.cpp:156-186): where the four texels are and how they are weighted.
+struct TexQuad { int x0, x1, y0, y1; float w00, w10, w01, w11; };
+RTX_D TexQuad tex_quad(const TexLevel & L, float s, float t) {
+    const float ps = s * L.wf - 0.5f, pt = t * L.hf - 0.5f;
+    const float fs = ps - floorf(ps), ft = pt - floorf(pt);
+    const float gs = 1.0f - fs, gt = 1.0f - ft;
+    TexQuad q;
+    q.w00 = gs * gt; q.w10 = fs * gt; q.w01 = gs * ft;
+    q.w11 = 1.0f - q.w00 - q.w10 - q.w01;
+    const int ix = f2i_rn_x86(ps - 0.5f), iy = f2i_rn_x86(pt - 0.5f);
+    q.x0 = tex_wrap(ix, L.w, L.mask_x); q.x1 = tex_wrap(ix + 1, L.w, L.mask_x);
+    q.y0 = tex_wrap(iy, L.h, L.mask_y); q.y1 = tex_wrap(iy + 1, L.h, L.mask_y);
+    return q;
 }
-
-RTX_D v3 sample_bilinear(TexCtx & tc, float s, float t, int level) {  // Texture.cpp:156-186
-    int lw = tc.t->desc.width >> level, lh = tc.t->desc.height >> level;
-    s = s * (float)lw - 0.5f;
-    t = t * (float)lh - 0.5f;
-    float fs = s - floorf(s);
-    float ft = t - floorf(t);
-    float oms = 1.0f - fs, omt = 1.0f - ft;
-    float w0 = oms * omt;
-    float w1 = fs  * omt;
-    float w2 = oms * ft;
-    float w3 = 1.0f - w0 - w1 - w2;
-    int is = f2i_rn_x86(s - 0.5f);
-    int it = f2i_rn_x86(t - 0.5f);
-    v3 r =      vmuls(fetch_texel(tc, is,     it,     level), w0);
-    r = vadd(r, vmuls(fetch_texel(tc, is + 1, it,     level), w1));
-    r = vadd(r, vmuls(fetch_texel(tc, is,     it + 1, level), w2));
-    r = vadd(r, vmuls(fetch_texel(tc, is + 1, it + 1, level), w3));
+struct TexQuadData { v3 c00, c10, c01, c11; };
+RTX_D TexQuadData tex_quad_fetch(TexCtx & tc, const TexLevel & L, const TexQuad & q) {      // four independent 16-byte loads
+    TexQuadData d;
+    d.c00 = tex_load(L, q.x0, q.y0); d.c10 = tex_load(L, q.x1, q.y0); d.c01 = tex_load(L, q.x0, q.y1); d.c11 = tex_load(L, q.x1, q.y1);
+    tc.fetches += 4;
+    return d;
+}
+RTX_D v3 tex_quad_blend(const TexQuad & q, const TexQuadData & d) {
+    v3 r = vmuls(d.c00, q.w00);
+    r = vadd(r, vmuls(d.c10, q.w10));
+    r = vadd(r, vmuls(d.c01, q.w01));
+    r = vadd(r, vmuls(d.c11, q.w11));
     return r;
 }
-
-RTX_D v3 sample_trilinear(TexCtx & tc, float s, float t, float ds_dx, float ds_dy, float dt_dx, float dt_dy) {  // Texture.cpp:189-204
-    const rtx_texture_desc & d = tc.t->desc;
-    float width = 2.0f * std_max(std_max(fabsf(ds_dx), fabsf(ds_dy)), std_max(fabsf(dt_dx), fabsf(dt_dy)));
-    float lambda = (float)d.mip_levels - 1.0f + rtx_log2f(std_max(width, 1e-8f));
-    int level = f2i_rn_x86(lambda - 0.5f);
-    if (level < 0) return sample_bilinear(tc, s, t, 0);
-    if (level >= d.mip_levels - 1) return fetch_texel(tc, 0, 0, d.mip_levels - 1);
-    float f = lambda - floorf(lambda);
-    return vadd(vmuls(sample_bilinear(tc, s, t, level), 1.0f - f), vmuls(sample_bilinear(tc, s, t, level + 1), f));
+RTX_D v3 tex_bilinear(TexCtx & tc, const TexLevel & L, float s, float t) {
+    const TexQuad q = tex_quad(L, s, t);
+    return tex_quad_blend(q, tex_quad_fetch(tc, L, q));
 }
 
-RTX_D v3 sample_anisotropic(TexCtx & tc, float max_aniso, float s, float t, float ds_dx, float ds_dy, float dt_dx, float dt_dy) {  // Texture.cpp:207-239
-    const rtx_texture_desc & d = tc.t->desc;
-    float p_x = std_max(fabsf(ds_dx), fabsf(dt_dx));
-    float p_y = std_max(fabsf(ds_dy), fabsf(dt_dy));
-    float p_min = std_min(p_x, p_y);
-    float p_max = std_max(p_x, p_y);
-    float N = std_min(ceilf(p_max / p_min), max_aniso);
-    float one_over_N = 1.0f / N;
-    float lambda = (float)d.mip_levels - 1.0f + rtx_log2f(p_max * one_over_N);
-    int level = f2i_rn_x86(lambda);
-    if (level < 0) return sample_bilinear(tc, s, t, 0);
-    if (level >= d.mip_levels - 1) return fetch_texel(tc, 0, 0, d.mip_levels - 1);
-    bool x_major = p_x > p_y;
-    float step_s = x_major ? ds_dx : ds_dy;
-    float step_t = x_major ? dt_dx : dt_dy;
-    float one_over_N_plus_1 = 1.0f / (N + 1.0f);
-    v3 sum = V3(0.0f, 0.0f, 0.0f);
-    for (float i = 1.0f; i <= N + 0.001f; i += 1.0f) {
-        float x = s + step_s * (i * one_over_N_plus_1 - 0.5f);
-        float y = t + step_t * (i * one_over_N_plus_1 - 0.5f);
-        sum = vadd(sum, sample_bilinear(tc, x, y, level));
-    }
-    return vmuls(sum, one_over_N);
+// Texture::sample_nearest, Texture.cpp:149-154
+RTX_D v3 tex_nearest(TexCtx & tc, float s, float t) {
+    const TexLevel L = tex_level(tc, 0);
+    return tex_texel(tc, L, f2i_rn_x86(s * L.wf), f2i_rn_x86(t * L.hf));
 }
 
-RTX_D v3 sample_ewa(TexCtx & tc, const float * ewa_table, float max_aniso, float s, float t, float ds_dx, float ds_dy, float dt_dx, float dt_dy) {  // Texture.cpp:242-337
+// the 1x1 top of the chain, which every mip filter returns beyond its last level
+RTX_D v3 tex_coarsest(TexCtx & tc) { const TexLevel L = tex_level(tc, tc.t->desc.mip_levels - 1); return tex_texel(tc, L, 0, 0); }
+
+// Texture::sample_mipmap_trilinear, Texture.cpp:189-204: both levels' footprints are fetched before either is blended
+RTX_D v3 tex_trilinear(TexCtx & tc, float s, float t, float ds_dx, float ds_dy, float dt_dx, float dt_dy) {
+    const int levels = tc.t->desc.mip_levels;
+    const float footprint = 2.0f * std_max(std_max(fabsf(ds_dx), fabsf(ds_dy)), std_max(fabsf(dt_dx), fabsf(dt_dy)));
+    const float lod = (float)levels - 1.0f + rtx_log2f(std_max(footprint, 1e-8f));
+    const int lo = f2i_rn_x86(lod - 0.5f);
+    if (lo < 0) return tex_bilinear(tc, tex_level(tc, 0), s, t);
+    if (lo >= levels - 1) return tex_coarsest(tc);
+    const TexLevel La = tex_level(tc, lo), Lb = tex_level(tc, lo + 1);
+    const TexQuad qa = tex_quad(La, s, t), qb = tex_quad(Lb, s, t);
+    const TexQuadData da = tex_quad_fetch(tc, La, qa), db = tex_quad_fetch(tc, Lb, qb);
+    const float frac = lod - floorf(lod);
+    return vadd(vmuls(tex_quad_blend(qa, da), 1.0f - frac), vmuls(tex_quad_blend(qb, db), frac));
+}
+
+// Texture::sample_mipmap_anisotropic, Texture.cpp:207-239: up to MAX_ANISOTROPY bilinear taps along the longer screen-space axis of
+// the footprint, on the level chosen by the shorter one.  Taps are fetched two at a time; they are ADDED in tap order.
+RTX_D v3 tex_anisotropic(TexCtx & tc, float max_taps, float s, float t, float ds_dx, float ds_dy, float dt_dx, float dt_dy) {
+    const int levels = tc.t->desc.mip_levels;
+    const float ext_x = std_max(fabsf(ds_dx), fabsf(dt_dx)), ext_y = std_max(fabsf(ds_dy), fabsf(dt_dy));
+    const float ext_short = std_min(ext_x, ext_y), ext_long = std_max(ext_x, ext_y);
+    const float taps = std_min(ceilf(ext_long / ext_short), max_taps);
+    const float inv_taps = 1.0f / taps;
+    const float lod = (float)levels - 1.0f + rtx_log2f(ext_long * inv_taps);
+    const int level = f2i_rn_x86(lod);
+    if (level < 0) return tex_bilinear(tc, tex_level(tc, 0), s, t);
+    if (level >= levels - 1) return tex_coarsest(tc);
+    const TexLevel L = tex_level(tc, level);
+    const bool along_x = ext_x > ext_y;
+    const float axis_s = along_x ? ds_dx : ds_dy, axis_t = along_x ? dt_dx : dt_dy;
+    const float spacing = 1.0f / (taps + 1.0f);
+    const float last = taps + 0.001f;
+    v3 acc = V3(0.0f, 0.0f, 0.0f);
+    for (float k = 1.0f; k <= last; k += 2.0f) {
+        const float ka = k, kb = k + 1.0f;                    // the tap counter advances by repeated += 1.0f in the reference: exact for these small integers
+        const bool second = kb <= last;
+        const float offa = ka * spacing - 0.5f, offb = kb * spacing - 0.5f;
+        const TexQuad qa = tex_quad(L, s + axis_s * offa, t + axis_t * offa);
+        const TexQuad qb = tex_quad(L, s + axis_s * offb, t + axis_t * offb);
+        const TexQuadData da = tex_quad_fetch(tc, L, qa);
+        TexQuadData db = da;
+        if (second) db = tex_quad_fetch(tc, L, qb);
+        acc = vadd(acc, tex_quad_blend(qa, da));
+        if (second) acc = vadd(acc, tex_quad_blend(qb, db));
+    }
+    return vmuls(acc, inv_taps);
+}
+
+// Texture::sample_mipmap_ewa, Texture.cpp:242-337: elliptical weighted average over the texels inside the unit ellipse of the pixel's
+// footprint, Gaussian weights from the 128-entry table of Texture::init (Texture.h:53-62).  Texels are visited row by row (a row's
+// wrap is computed once) and accumulated in that order.
+RTX_D v3 tex_ewa(TexCtx & tc, const float * lut, float max_ratio, float s, float t, float ds_dx, float ds_dy, float dt_dx, float dt_dy) {
     const rtx_texture_desc & d = tc.t->desc;
-    float major_x = ds_dx, major_y = dt_dx;
-    float minor_x = ds_dy, minor_y = dt_dy;
-    float major_length = sqrtf(major_x * major_x + major_y * major_y);
-    float minor_length = sqrtf(minor_x * minor_x + minor_y * minor_y);
-    if (minor_length > major_length) {
-        float tx = minor_x, ty = minor_y, tl = minor_length;
-        minor_x = major_x; minor_y = major_y; minor_length = major_length;
-        major_x = tx; major_y = ty; major_length = tl;
-    }
-    if (minor_length < 0.00001f) return sample_bilinear(tc, s, t, 0);
-    if (major_length > (float)d.width) return fetch_texel(tc, 0, 0, d.mip_levels - 1);
-    if (minor_length * max_aniso < major_length) {
-        float scale = major_length / (minor_length * max_aniso);
-        minor_x *= scale; minor_y *= scale;
-        minor_length *= scale;
-    }
-    float lambda = std_max(0.0f, (float)d.mip_levels - 1.0f + rtx_log2f(minor_length));
-    int level = f2i_rn_x86(lambda);
-    if (level >= d.mip_levels - 1) return fetch_texel(tc, 0, 0, d.mip_levels - 1);
-    float level_width  = (float)(d.width  >> level);
-    float level_height = (float)(d.height >> level);
-    s = s * level_width  - 0.5f;
-    t = t * level_height - 0.5f;
-    float majx = major_x * level_width, majy = major_y * level_height;
-    float minx = minor_x * level_width, miny = minor_y * level_height;
-    float a =  1.0f + (majy * majy + miny * miny);
-    float b = -2.0f * (majx * majy + minx * miny);
-    float c =  1.0f + (majx * majx + minx * minx);
-    float one_over_f = 1.0f / (a * c - b * b * 0.25f);
-    a *= one_over_f; b *= one_over_f; c *= one_over_f;
-    float det = -b * b + 4.0f * a * c;
-    float sqrt_u = sqrtf(det * c);
-    float sqrt_v = sqrtf(det * a);
-    float two_inv_det = 2.0f / det;
-    float tu = two_inv_det * sqrt_u;
-    float tv = two_inv_det * sqrt_v;
-    int s0 = f2i_rn_x86(s - tu + 0.5f);
-    int s1 = f2i_rn_x86(s + tu - 0.5f);
-    int t0 = f2i_rn_x86(t - tv + 0.5f);
-    int t1 = f2i_rn_x86(t + tv - 0.5f);
-    v3 sum = V3(0.0f, 0.0f, 0.0f);
-    float sum_weights = 0.0f;
-    float tf = (float)t0;
-    const float s0f = (float)s0;
-    for (int ti = t0; ti <= t1; ti++, tf += 1.0f) {
-        float tt = tf - t;
-        float sf = s0f;
-        for (int si = s0; si <= s1; si++, sf += 1.0f) {
-            float ss = sf - s;
-            float r2 = a * ss * ss + b * ss * tt + c * tt * tt;
+    float ax = ds_dx, ay = dt_dx, bx = ds_dy, by = dt_dy;                    // the two axes of the footprint; a becomes the major one
+    float alen = sqrtf(ax * ax + ay * ay), blen = sqrtf(bx * bx + by * by);
+    if (blen > alen) { const float x = bx, y = by, l = blen; bx = ax; by = ay; blen = alen; ax = x; ay = y; alen = l; }
+    if (blen < 0.00001f) return tex_bilinear(tc, tex_level(tc, 0), s, t);
+    if (alen > (float)d.width) return tex_coarsest(tc);
+    if (blen * max_ratio < alen) { const float k = alen / (blen * max_ratio); bx *= k; by *= k; blen *= k; }      // clamp the eccentricity
+    const float lod = std_max(0.0f, (float)d.mip_levels - 1.0f + rtx_log2f(blen));
+    const int level = f2i_rn_x86(lod);
+    if (level >= d.mip_levels - 1) return tex_coarsest(tc);
+    const TexLevel L = tex_level(tc, level);
+    const float cs = s * L.wf - 0.5f, ct = t * L.hf - 0.5f;                 // ellipse centre in texels
+    const float Ax = ax * L.wf, Ay = ay * L.hf, Bx = bx * L.wf, By = by * L.hf;
+    float qa =  1.0f + (Ay * Ay + By * By);                                  // implicit ellipse qa*u^2 + qb*u*v + qc*v^2 < 1
+    float qb = -2.0f * (Ax * Ay + Bx * By);
+    float qc =  1.0f + (Ax * Ax + Bx * Bx);
+    const float norm = 1.0f / (qa * qc - qb * qb * 0.25f);
+    qa *= norm; qb *= norm; qc *= norm;
+    const float det = -qb * qb + 4.0f * qa * qc;
+    const float half_w = (2.0f / det) * sqrtf(det * qc), half_h = (2.0f / det) * sqrtf(det * qa);      // bounding box of the ellipse
+    const int x_lo = f2i_rn_x86(cs - half_w + 0.5f), x_hi = f2i_rn_x86(cs + half_w - 0.5f);
+    const int y_lo = f2i_rn_x86(ct - half_h + 0.5f), y_hi = f2i_rn_x86(ct + half_h - 0.5f);
+    v3 acc = V3(0.0f, 0.0f, 0.0f);
+    float wsum = 0.0f;
+    float yf = (float)y_lo;
+    const float xf0 = (float)x_lo;
+    for (int y = y_lo; y <= y_hi; y++, yf += 1.0f) {
+        const float v = yf - ct;
+        const int row = tex_wrap(y, L.h, L.mask_y) * L.w;
+        float xf = xf0;
+        for (int x = x_lo; x <= x_hi; x++, xf += 1.0f) {
+            const float u = xf - cs;
+            const float r2 = qa * u * u + qb * u * v + qc * v * v;
             if (r2 < 1.0f) {
-                int idx = f2i_rn_x86(r2 * (float)RTX_EWA_LUT_SIZE);
-                if (RTX_EWA_LUT_SIZE - 1 < idx) idx = RTX_EWA_LUT_SIZE - 1;
-                float weight = ewa_table[idx];
-                sum = vadd(sum, vmuls(fetch_texel(tc, si, ti, level), weight));
-                sum_weights += weight;
+                int slot = f2i_rn_x86(r2 * (float)RTX_EWA_LUT_SIZE);
+                if (RTX_EWA_LUT_SIZE - 1 < slot) slot = RTX_EWA_LUT_SIZE - 1;
+                const float w = lut[slot];
+                const float4 c = gld(L.base, tex_wrap(x, L.w, L.mask_x) + row);
+                tc.fetches++;
+                acc = vadd(acc, vmuls(V3(c.x, c.y, c.z), w));
+                wsum += w;
             }
         }
     }
-    return vdivs(sum, sum_weights);
+    return vdivs(acc, wsum);
 }
 
-// Texture::sample, Texture.h:33-49 (compile-time switches of Config.h:38-53 become runtime fields)
+// Texture::sample, Texture.h:33-49 (the compile-time switches of Config.h:38-53 are run-time fields of the context)
 RTX_D v3 texture_sample(TexCtx & tc, const DevScene & sc, float s, float t, float ds_dx, float ds_dy, float dt_dx, float dt_dy) {
-    if (sc.texture_mode == RTX_TEXTURE_NEAREST)  return sample_nearest(tc, s, t);
-    if (sc.texture_mode == RTX_TEXTURE_BILINEAR) return sample_bilinear(tc, s, t, 0);
-    if (!tc.t->desc.mipmapped) return sample_bilinear(tc, s, t, 0);
-    if (sc.mip_filter == RTX_MIP_TRILINEAR)   return sample_trilinear(tc, s, t, ds_dx, ds_dy, dt_dx, dt_dy);
-    if (sc.mip_filter == RTX_MIP_ANISOTROPIC) return sample_anisotropic(tc, sc.max_anisotropy, s, t, ds_dx, ds_dy, dt_dx, dt_dy);
-    return sample_ewa(tc, sc.ewa_table, sc.max_anisotropy, s, t, ds_dx, ds_dy, dt_dx, dt_dy);
+    if (sc.texture_mode == RTX_TEXTURE_NEAREST)  return tex_nearest(tc, s, t);
+    if (sc.texture_mode == RTX_TEXTURE_BILINEAR || !tc.t->desc.mipmapped) return tex_bilinear(tc, tex_level(tc, 0), s, t);
+    if (sc.mip_filter == RTX_MIP_TRILINEAR)   return tex_trilinear(tc, s, t, ds_dx, ds_dy, dt_dx, dt_dy);
+    if (sc.mip_filter == RTX_MIP_ANISOTROPIC) return tex_anisotropic(tc, sc.max_anisotropy, s, t, ds_dx, ds_dy, dt_dx, dt_dy);
+    return tex_ewa(tc, sc.ewa_table, sc.max_anisotropy, s, t, ds_dx, ds_dy, dt_dx, dt_dy);
 }
 
 // Sky::sample, Sky.cpp:28-68 at lane 1 (truncating float->int, inclusive upper clamp)

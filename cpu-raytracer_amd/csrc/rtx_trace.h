@@ -45,10 +45,6 @@
 #ifndef RTX_NANFREE_CLOSEST
 #define RTX_NANFREE_CLOSEST 0    // same for the closest-hit kernel (costs it registers: 119 -> 139 VGPRs, one wave per SIMD less)
 #endif
-typedef float rtx_f4v __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(1))) rtx_f4v * rtx_gptr;
-#define RTX_GPTR(p) ((rtx_gptr)(const void *)(p))
-RTX_D float4 gld(rtx_gptr p, int i) { const rtx_f4v v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 
 // Slot -> pixel of a primary ray.  1024 slots per tile, a wave covers an 8x8 pixel block.
 RTX_D bool primary_pixel(const DevScene & sc, const DevQueues & q, uint32_t slot, int & px, int & py) {
@@ -164,6 +160,16 @@ RTX_D float plane_t(const rtx_plane & pl, v3 o, v3 d) {
     return -(vdot(n, o) + pl.distance) / vdot(n, d);
 }
 
+// Shadow queue of a level: one slot per ray of the level and light (slot = the ray's own index: k_shade does not compact), of which
+// only the rays with a lit hit carry a shadow ray — NF_LIT in the node record k_shade wrote.
+RTX_D uint32_t shadow_slots(const DevCounters * ctr, const DevQueues & q, int level) {
+    const uint32_t n = ctr->ray_count[level], cap = (uint32_t)q.level_cap[level];
+    return n < cap ? n : cap;
+}
+RTX_D bool shadow_slot_is_lit(const DevQueues & q, int level, uint32_t rank) {
+    return (as_i(q.n0[(uint32_t)q.level_base[level] + rank].w) & NF_LIT) != 0;
+}
+
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(RTX_TRACE_BLOCK)
 void k_trace(const DevScene sc, const DevQueues q, const int level) {
@@ -176,10 +182,10 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
     const int spill_stride = q.spill_threads;
 
     DevCounters * const ctr = q.counters;
-    const uint32_t total = ANY ? ctr->lit_count[level] * (uint32_t)sc.light_count : ctr->ray_count[level];
+    const uint32_t total = ANY ? shadow_slots(ctr, q, level) * (uint32_t)sc.light_count : ctr->ray_count[level];
     uint32_t * const head = ANY ? &ctr->fetch_any[level] : &ctr->fetch_closest[level];
     const int lit_cap = q.level_cap[level];
-    const uint32_t lit_n = ctr->lit_count[level];
+    const uint32_t lit_n = shadow_slots(ctr, q, level);
 
     // per-lane ray state
     bool has_ray = false;
@@ -232,8 +238,8 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
                     // shadow slot order: light-major within the level, idx = light * lit_n + rank
                     const uint32_t light = idx / lit_n, rank = idx - light * lit_n;
                     out_slot = (uint32_t)q.shadow_base[level] + light * (uint32_t)lit_cap + rank;
-                    const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot];
-                    wo = V3(s0.x, s0.y, s0.z); tcur = s0.w; wd = V3(s1.x, s1.y, s1.z);
+                    live = shadow_slot_is_lit(q, level, rank);
+                    if (live) { const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot]; wo = V3(s0.x, s0.y, s0.z); tcur = s0.w; wd = V3(s1.x, s1.y, s1.z); }
                 } else {
                     out_slot = (uint32_t)q.level_base[level] + idx;
                     if (level == 0) {
@@ -411,7 +417,7 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
     DevCounters * const ctr = q.counters;
     // shadow rays: one launch may cover the levels [level, level_hi]; closest-hit rays: exactly one level
     uint32_t total = 0;
-    if (ANY) { for (int d = level; d <= level_hi; d++) total += ctr->lit_count[d] * (uint32_t)sc.light_count; }
+    if (ANY) { for (int d = level; d <= level_hi; d++) total += shadow_slots(ctr, q, d) * (uint32_t)sc.light_count; }
     else total = ctr->ray_count[level];
     uint32_t * const head = ANY ? &ctr->fetch_any[level] : &ctr->fetch_closest[level];
     const bool ordered = sc.traversal_strategy == RTX_TRAVERSE_ORDERED;
@@ -470,12 +476,12 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
                 if (ANY) {
                     // idx -> (level, light, rank): levels are concatenated, light-major inside a level
                     uint32_t local = idx; int d = level;
-                    uint32_t lit_n = ctr->lit_count[d];
-                    while (d < level_hi && local >= lit_n * (uint32_t)sc.light_count) { local -= lit_n * (uint32_t)sc.light_count; d++; lit_n = ctr->lit_count[d]; }
+                    uint32_t lit_n = shadow_slots(ctr, q, d);
+                    while (d < level_hi && local >= lit_n * (uint32_t)sc.light_count) { local -= lit_n * (uint32_t)sc.light_count; d++; lit_n = shadow_slots(ctr, q, d); }
                     const uint32_t light = local / lit_n, rank = local - light * lit_n;
                     out_slot = (uint32_t)q.shadow_base[d] + light * (uint32_t)q.level_cap[d] + rank;
-                    const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot];
-                    wo = V3(s0.x, s0.y, s0.z); tcur = s0.w; wd = V3(s1.x, s1.y, s1.z);
+                    live = shadow_slot_is_lit(q, d, rank);
+                    if (live) { const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot]; wo = V3(s0.x, s0.y, s0.z); tcur = s0.w; wd = V3(s1.x, s1.y, s1.z); }
                     if (tcur < 0.0f) live = false;        // culled by k_shade<.., CULL>: contribution is exactly zero, already resolved
                 } else {
                     out_slot = (uint32_t)q.level_base[level] + idx;
