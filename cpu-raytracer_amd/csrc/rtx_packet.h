@@ -637,8 +637,14 @@ RTX_D void pk_lane_phase_any(PkWalk & W, const int lane, int * const stk, int * 
         else { W.err = 1; return; }
         psp++;
     };
+#ifdef RTX_PK_PROF
+    unsigned long long lane_iters = 0;
+#endif
     for (;;) {
         if (__ballot(live && (have_cur || psp > 0)) == 0ull) break;
+#ifdef RTX_PK_PROF
+        lane_iters++;
+#endif
         // inner node: child-pair gather, both slab tests, descend left, push right (any order is exact for any-hit rays)
         if (live && have_cur && (cur_cnt & 0x3fffffff) == 0) {
             const int left = cur_first;
@@ -687,6 +693,10 @@ RTX_D void pk_lane_phase_any(PkWalk & W, const int lane, int * const stk, int * 
     }
     W.alive &= __ballot(live);            // lanes that found an occluder leave the packet
     W.psp = 0;
+#ifdef RTX_PK_PROF
+    if (lane_iters > W.prof[9]) W.prof[9] = lane_iters;       // slot 9: most iterations of one per-lane phase
+    if ((unsigned long long)W.pk_steps > W.prof[5]) W.prof[5] = (unsigned long long)W.pk_steps;   // slot 5: most packet steps of one walk
+#endif
 }
 
 // ---- hybrid closest-hit walk, per-lane phase ----------------------------------------------------------------------------------
@@ -1009,6 +1019,8 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
             if (!got) break;
         }
 
+        if (q.pk_order == 1) pk = npk - 1u - pk;                                   // experiment: reverse order
+        else if (q.pk_order == 2) pk = (uint32_t)(((unsigned long long)pk * 2654435761ull) % npk);      // experiment: scattered order (not a permutation: timing only)
         // ---------------- the packet's rays ----------------
         W.valid = false; W.occluded = false;
         uint32_t out_slot = 0;
@@ -1092,7 +1104,6 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
             {   // slot 4: the longest single packet walk (max), slot 9: walks longer than 2^18 ticks
                 const unsigned long long dt = __builtin_amdgcn_s_memtime() - pk_w0_;
                 if (dt > W.prof[4]) W.prof[4] = dt;
-                if (dt > (1ull << 18)) W.prof[9]++;
             }
 #endif
         }
@@ -1108,7 +1119,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
     W.prof[6] = __builtin_amdgcn_s_memtime() - pk_k0_;          // this wave's lifetime
     W.prof[7] = __builtin_amdgcn_s_memtime();                    // last end (max)
     W.prof[8] = (1ull << 62) - pk_k0_;                           // first start (max of the complement)
-    if (lane == 0) for (int i = 0; i < 10; i++) { if (i == 4 || i == 7 || i == 8) atomicMax(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); else atomicAdd(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); }
+    if (lane == 0) for (int i = 0; i < 10; i++) { if (i == 4 || i == 5 || i == 7 || i == 8 || i == 9) atomicMax(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); else atomicAdd(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); }
 #endif
     if (W.err) { if (lane == 0) atomicOr(&ctr->error_flags, ERR_STACK_OVERFLOW); }
     if (PSTAT && lane == 0) {

@@ -20,4 +20,5 @@ for kind, off in (("any", 0), ("closest", 10)):
         c, k = raw[off + i], raw[off + 5 + i]
         print("   %-8s %14d ticks %5.1f%%  count %9d  ticks/call %8.1f" % (n, c, 100.0 * c / max(tot, 1), k, c / max(k, 1)))
     span = raw[off + 7] - ((1 << 62) - raw[off + 8])
+    print("   max packet steps of one walk %d, max iterations of one per-lane phase %d" % (raw[off + 5], raw[off + 9]))
     print("   kernel span %d ticks (first wave start -> last wave end); sum of wave lifetimes %d ticks = %.1f waves busy on average" % (span, raw[off + 6], raw[off + 6] / max(span, 1)))
