@@ -199,7 +199,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     if (c->pk_blocks_closest > max_blocks) max_blocks = c->pk_blocks_closest;
     c->q.pk_defer_t0 = 8; if (const char * e = getenv("RTX_PK_DEFER")) c->q.pk_defer_t0 = atoi(e);
     c->q.pk_defer_t0_closest = 64; if (const char * e = getenv("RTX_PK_DEFER_CLOSEST")) c->q.pk_defer_t0_closest = atoi(e);
-    if (const char * e = getenv("RTX_PK_ORDER")) c->q.pk_order = atoi(e);
+    c->q.pk_order = 1; if (const char * e = getenv("RTX_PK_ORDER")) c->q.pk_order = atoi(e);
     c->q.pk_defer_grow = 3; if (const char * e = getenv("RTX_PK_GROW")) c->q.pk_defer_grow = atoi(e);
     c->q.spill_threads = max_blocks * RTX_TRACE_BLOCK;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast

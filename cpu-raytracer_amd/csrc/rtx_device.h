@@ -132,7 +132,7 @@ struct DevQueues {
     int32_t *     spill;          // traversal stack spill, 3 regions of [(entry - RTX_LDS_STACK) * spill_threads + thread]: closest entries, closest keys, shadow entries
     int32_t       spill_threads;
     int32_t *     pk_fifo;        // closest-hit hybrid walk: per-lane work lists, [RTX_PK_FIFO entries][spill_threads] (rtx_packet.h)
-    int32_t       pk_order;       // experiments: 0 packets in queue order, 1 reversed
+    int32_t       pk_order;       // shadow-ray packets: 1 = last level first (default), 0 = queue order
     int32_t       pk_defer_grow;  // ... threshold = pk_defer_t0 + (steps of this packet walk >> pk_defer_grow)
     int32_t       pk_defer_t0_closest;   // the same threshold for closest-hit packets (64 = every lane walks its ray privately from the BLAS root)
     int32_t       pk_defer_t0;    // hybrid any-hit walk: nodes wanted by at most this many lanes (+ walk length / 8) go to the lanes' private stacks

@@ -1019,8 +1019,9 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
             if (!got) break;
         }
 
-        if (q.pk_order == 1) pk = npk - 1u - pk;                                   // experiment: reverse order
-        else if (q.pk_order == 2) pk = (uint32_t)(((unsigned long long)pk * 2654435761ull) % npk);      // experiment: scattered order (not a permutation: timing only)
+        // shadow-ray launches walk their packets last level first: the packets of the deeper levels are the incoherent, expensive ones
+        // (longest jobs first: 0.79 -> 0.73 ms for the merged launch); RTX_PK_ORDER=0 restores queue order
+        if (ANY && q.pk_order != 0) pk = npk - 1u - pk;
         // ---------------- the packet's rays ----------------
         W.valid = false; W.occluded = false;
         uint32_t out_slot = 0;
