@@ -151,27 +151,27 @@ RTX_D void pk_push(PkWalk & W, int a, int b, unsigned long long mask, int idx, i
 // loop of the FAST walk (finite inverse directions: v_min / v_max semantics equal the reference's on non-NaN operands) written as
 // one asm block, because the compiler keeps the wave-uniform state of this loop in VGPRs (selects through v_cndmask, address
 // arithmetic on the VALU, copies of the stack registers at every join): 124 VALU instructions per step compiled vs 34 + 5 here.
-//   SGPR temporaries s[64:95] (child pair in s[64:79]), VGPR temporaries v[84:93]; both are declared as clobbers.
+//   SGPR temporaries s[64:95] (child pair in s[64:79]), VGPR temporaries v[24:31]; both are declared as clobbers.
 //   Hazards (gfx940/950 table): every VALU -> VALU dependency is through VGPRs (interlocked); VCC written by v_cmp is read by SALU
 //   only (interlocked); M0 is written by SALU before v_writelane (no wait state required, one s_nop kept); no trans ops, no DPP.
 #define PK_ASM_SLAB(X0, X1, X2, X3, X4, X5, MASK)                                                                                   \
-    "v_pk_add_f32 v[84:85], s[" #X0 ":" #X1 "], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                              \
-    "v_pk_add_f32 v[86:87], s[" #X2 ":" #X3 "], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                              \
-    "v_pk_add_f32 v[88:89], s[" #X4 ":" #X5 "], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                              \
-    "v_pk_mul_f32 v[84:85], %[ixy], v[84:85]\n\t"                                                                                   \
-    "v_pk_mul_f32 v[86:87], %[ixy], v[86:87]\n\t"                                                                                   \
-    "v_pk_mul_f32 v[88:89], %[izz], v[88:89]\n\t"                                                                                   \
-    "v_min_f32 v90, v84, v86\n\t"                                                                                                   \
-    "v_max_f32 v84, v84, v86\n\t"                                                                                                   \
-    "v_min_f32 v91, v85, v87\n\t"                                                                                                   \
-    "v_max_f32 v85, v85, v87\n\t"                                                                                                   \
-    "v_min_f32 v86, v88, v89\n\t"                                                                                                   \
-    "v_max_f32 v87, v88, v89\n\t"                                                                                                   \
-    "v_max3_f32 v90, v90, v91, v86\n\t"                                                                                             \
-    "v_min3_f32 v84, v84, v85, v87\n\t"                                                                                             \
-    "v_max_f32 v90, %[eps], v90\n\t"                                                                                                \
-    "v_min_f32 v84, %[tcur], v84\n\t"                                                                                               \
-    "v_cmp_lt_f32 vcc, v90, v84\n\t"                                                                                                \
+    "v_pk_add_f32 v[24:25], s[" #X0 ":" #X1 "], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                              \
+    "v_pk_add_f32 v[26:27], s[" #X2 ":" #X3 "], %[oxy] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                              \
+    "v_pk_add_f32 v[28:29], s[" #X4 ":" #X5 "], %[ozz] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                              \
+    "v_pk_mul_f32 v[24:25], %[ixy], v[24:25]\n\t"                                                                                   \
+    "v_pk_mul_f32 v[26:27], %[ixy], v[26:27]\n\t"                                                                                   \
+    "v_pk_mul_f32 v[28:29], %[izz], v[28:29]\n\t"                                                                                   \
+    "v_min_f32 v30, v24, v26\n\t"                                                                                                   \
+    "v_max_f32 v24, v24, v26\n\t"                                                                                                   \
+    "v_min_f32 v31, v25, v27\n\t"                                                                                                   \
+    "v_max_f32 v25, v25, v27\n\t"                                                                                                   \
+    "v_min_f32 v26, v28, v29\n\t"                                                                                                   \
+    "v_max_f32 v27, v28, v29\n\t"                                                                                                   \
+    "v_max3_f32 v30, v30, v31, v26\n\t"                                                                                             \
+    "v_min3_f32 v24, v24, v25, v27\n\t"                                                                                             \
+    "v_max_f32 v30, %[eps], v30\n\t"                                                                                                \
+    "v_min_f32 v24, %[tcur], v24\n\t"                                                                                               \
+    "v_cmp_lt_f32 vcc, v30, v24\n\t"                                                                                                \
     "s_and_b64 " MASK ", vcc, %[m]\n\t"
 
 template <bool ANY>
@@ -264,7 +264,7 @@ RTX_D void pk_descend(PkWalk & W, int stack_size, int ordered, int thr) {
             : "vcc", "scc", "m0",
               "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
               "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
-              "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+              "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
     } else {
         asm volatile(
             "s_mov_b64 s[94:95], %[nodes]\n\t"
@@ -375,7 +375,7 @@ RTX_D void pk_descend(PkWalk & W, int stack_size, int ordered, int thr) {
             : "vcc", "scc", "m0",
               "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
               "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
-              "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+              "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
     }
     W.pk_steps = steps;
 }
@@ -388,7 +388,7 @@ RTX_D void pk_descend(PkWalk & W, int stack_size, int ordered, int thr) {
 // arithmetic: a lane that is hit leaves W.alive (the caller derives the per-lane flag from the masks).
 //   stack entry: a = first, b = count | depth << 16 (leaf counts < 65536 and node / triangle offsets < 2^31 are checked at upload)
 //   SGPRs: s[64:79] child pair / triangle, s[80:83] child masks, s[84:93] temporaries, s[94:97] node and triangle base addresses,
-//   s98/s99 triangle loop; VGPRs: v[84:91] slab pairs / temporaries, the rest are compiler-allocated operands.
+//   s98/s99 triangle loop; VGPRs: v[24:31] slab pairs / temporaries, the rest are compiler-allocated operands.
 //   Instruction budget per inner step: 34 VALU (+4 v_writelane on a push), 16-24 SALU.
 //   Hazards (gfx940/950): v_rcp_f32 (trans) result is used two instructions later; v_div_scale writes VCC four instructions before
 //   v_div_fmas reads it; SGPRs written by v_cmp are read by SALU only; v_readlane results are consumed by SALU / SMEM (interlocked).
@@ -500,13 +500,13 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
         "v_mul_f32 %[t3], s74, %[dx]\n\t"
         "v_mul_f32 %[t4], s73, %[dx]\n\t"
         "v_mul_f32 %[t5], s72, %[dy]\n\t"
-        "v_sub_f32 v84, %[t0], %[t1]\n\t"                    // h.x
-        "v_sub_f32 v85, %[t2], %[t3]\n\t"                    // h.y
-        "v_sub_f32 v86, %[t4], %[t5]\n\t"                    // h.z
+        "v_sub_f32 v24, %[t0], %[t1]\n\t"                    // h.x
+        "v_sub_f32 v25, %[t2], %[t3]\n\t"                    // h.y
+        "v_sub_f32 v26, %[t4], %[t5]\n\t"                    // h.z
         // a = e1.x*h.x + (e1.y*h.y + e1.z*h.z)
-        "v_mul_f32 %[t0], s69, v85\n\t"
-        "v_mul_f32 %[t1], s70, v86\n\t"
-        "v_mul_f32 %[t2], s68, v84\n\t"
+        "v_mul_f32 %[t0], s69, v25\n\t"
+        "v_mul_f32 %[t1], s70, v26\n\t"
+        "v_mul_f32 %[t2], s68, v24\n\t"
         "v_add_f32 %[t0], %[t0], %[t1]\n\t"
         "v_add_f32 %[t9], %[t2], %[t0]\n\t"                  // a
         // f = 1.0f / a, correctly rounded (the expansion hipcc emits for IEEE division with denormals enabled)
@@ -514,21 +514,21 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
         "v_rcp_f32 %[t1], %[t0]\n\t"
         "v_div_scale_f32 %[t2], vcc, 1.0, %[t9], 1.0\n\t"
         // s = o - p0 (independent work in the shadow of the rcp)
-        "v_subrev_f32 v87, s64, %[ox]\n\t"
+        "v_subrev_f32 v27, s64, %[ox]\n\t"
         "v_fma_f32 %[t3], -%[t0], %[t1], 1.0\n\t"
         "v_fmac_f32 %[t1], %[t3], %[t1]\n\t"
         "v_mul_f32 %[t4], %[t2], %[t1]\n\t"
         "v_fma_f32 %[t5], -%[t0], %[t4], %[t2]\n\t"
         "v_fmac_f32 %[t4], %[t5], %[t1]\n\t"
         "v_fma_f32 %[t0], -%[t0], %[t4], %[t2]\n\t"
-        "v_subrev_f32 v88, s65, %[oy]\n\t"
+        "v_subrev_f32 v28, s65, %[oy]\n\t"
         "v_div_fmas_f32 %[t0], %[t0], %[t1], %[t4]\n\t"
-        "v_subrev_f32 v89, s66, %[oz]\n\t"
+        "v_subrev_f32 v29, s66, %[oz]\n\t"
         "v_div_fixup_f32 %[t8], %[t0], %[t9], 1.0\n\t"       // f
         // u = f * (s.x*h.x + (s.y*h.y + s.z*h.z))
-        "v_mul_f32 %[t0], v88, v85\n\t"
-        "v_mul_f32 %[t1], v89, v86\n\t"
-        "v_mul_f32 %[t2], v87, v84\n\t"
+        "v_mul_f32 %[t0], v28, v25\n\t"
+        "v_mul_f32 %[t1], v29, v26\n\t"
+        "v_mul_f32 %[t2], v27, v24\n\t"
         "v_add_f32 %[t0], %[t0], %[t1]\n\t"
         "v_add_f32 %[t0], %[t2], %[t0]\n\t"
         "v_mul_f32 %[t7], %[t8], %[t0]\n\t"                  // u
@@ -539,26 +539,26 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
         "s_cmp_lg_u64 s[84:85], 0\n\t"
         "s_cbranch_scc0 PKB_NEXT_%=\n\t"                     // no lane of the node passes the u test
         // q = cross(s, e1)
-        "v_mul_f32 %[t0], s70, v88\n\t"
-        "v_mul_f32 %[t1], s69, v89\n\t"
-        "v_mul_f32 %[t2], s68, v89\n\t"
-        "v_mul_f32 %[t3], s70, v87\n\t"
-        "v_mul_f32 %[t4], s69, v87\n\t"
-        "v_mul_f32 %[t5], s68, v88\n\t"
-        "v_sub_f32 v84, %[t0], %[t1]\n\t"                    // q.x  (h is dead)
-        "v_sub_f32 v85, %[t2], %[t3]\n\t"                    // q.y
-        "v_sub_f32 v86, %[t4], %[t5]\n\t"                    // q.z
+        "v_mul_f32 %[t0], s70, v28\n\t"
+        "v_mul_f32 %[t1], s69, v29\n\t"
+        "v_mul_f32 %[t2], s68, v29\n\t"
+        "v_mul_f32 %[t3], s70, v27\n\t"
+        "v_mul_f32 %[t4], s69, v27\n\t"
+        "v_mul_f32 %[t5], s68, v28\n\t"
+        "v_sub_f32 v24, %[t0], %[t1]\n\t"                    // q.x  (h is dead)
+        "v_sub_f32 v25, %[t2], %[t3]\n\t"                    // q.y
+        "v_sub_f32 v26, %[t4], %[t5]\n\t"                    // q.z
         // v = f * (d.x*q.x + (d.y*q.y + d.z*q.z))
-        "v_mul_f32 %[t0], %[dy], v85\n\t"
-        "v_mul_f32 %[t1], %[dz], v86\n\t"
-        "v_mul_f32 %[t2], %[dx], v84\n\t"
+        "v_mul_f32 %[t0], %[dy], v25\n\t"
+        "v_mul_f32 %[t1], %[dz], v26\n\t"
+        "v_mul_f32 %[t2], %[dx], v24\n\t"
         "v_add_f32 %[t0], %[t0], %[t1]\n\t"
         "v_add_f32 %[t0], %[t2], %[t0]\n\t"
         "v_mul_f32 %[t6], %[t8], %[t0]\n\t"                  // v
         // t = f * (e2.x*q.x + (e2.y*q.y + e2.z*q.z))
-        "v_mul_f32 %[t0], s73, v85\n\t"
-        "v_mul_f32 %[t1], s74, v86\n\t"
-        "v_mul_f32 %[t2], s72, v84\n\t"
+        "v_mul_f32 %[t0], s73, v25\n\t"
+        "v_mul_f32 %[t1], s74, v26\n\t"
+        "v_mul_f32 %[t2], s72, v24\n\t"
         "v_add_f32 %[t0], %[t0], %[t1]\n\t"
         "v_add_f32 %[t0], %[t2], %[t0]\n\t"
         "v_mul_f32 %[t5], %[t8], %[t0]\n\t"                  // t
@@ -612,7 +612,7 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
         : "vcc", "scc", "m0", "memory",
           "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
           "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
-          "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+          "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
     W.depth = depth; W.pk_steps = steps;
     if (maxd + 2 > stack_size || err) W.err = 1;       // reference stack: `depth` pending + 2 pushed at the deepest inner node expanded
 }

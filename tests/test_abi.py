@@ -70,3 +70,13 @@ def test_missing_extension_fails_loudly(tmp_path):
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
                 text = open(os.path.join(root, f), errors="replace").read()
                 assert not re.search(r"^\s*(import orc|from orc )|#\s*include[^\n]*rt_oracle|liboracle\.so", text, re.M), os.path.join(root, f)
+
+
+def test_integration_md_quotes_the_compiled_binding_verbatim():
+    """INTEGRATION.md's GpuBackend.cpp is the file `make -C oracle/ref_harness binding_check` compiles against the reference's headers."""
+    import os
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = open(os.path.join(repo, "cpu-raytracer_amd", "host", "reference_binding", "GpuBackend.cpp")).read()
+    assert code in open(os.path.join(repo, "INTEGRATION.md")).read()
+    mk = open(os.path.join(repo, "oracle", "ref_harness", "Makefile")).read()
+    assert "binding_check:" in mk and "reference_binding/GpuBackend.cpp" in mk
