@@ -1016,3 +1016,145 @@ extern "C" int rtx_debug_group_loopback(rtx_ctx * c, int32_t world, uint32_t fla
     if (g.recv.p) hipFree(g.recv.p);
     return rc;
 }
+
+// ---- unit-level entry points, second set: the traversal / hit / light / plot functions at caller-supplied inputs -------------------
+// rtx_debug_trace_rays: n rays (18 floats: origin, direction, dO_dx, dO_dy, dD_dx, dD_dy) through Scene::trace_primitives as the frame
+// kernels do it (the level-1 ray queue, the production closest-hit kernel, the accept-branch rebuild of k_shade), all RayHit fields out
+// (27 floats, layout of oracle orc_trace_closest); rtx_debug_occluded: Scene::intersect_primitives through the production shadow-ray
+// kernel (the level-0 shadow queue of light 0).
+__global__ void k_debug_fill_rays(DevQueues q, const float * rays, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { q.counters->ray_count[1] = (uint32_t)n; }
+    if (i >= n) return;
+    const float * r = rays + 18 * (size_t)i;
+    const uint32_t s = (uint32_t)q.level_base[1] + (uint32_t)i;
+    q.r0[s] = make_float4(r[0], r[1], r[2], r[3]); q.r1[s] = make_float4(r[4], r[5], r[6], r[7]);
+    q.r2[s] = make_float4(r[8], r[9], r[10], r[11]); q.r3[s] = make_float4(r[12], r[13], r[14], r[15]);
+    q.r4[s] = make_float4(r[16], r[17], 0.0f, 0.0f);
+}
+__global__ void k_debug_rebuild(DevScene sc, DevQueues q, const float * rays, float * out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float * r = rays + 18 * (size_t)i;
+    RayFull ray;
+    ray.o = V3(r[0], r[1], r[2]); ray.d = V3(r[3], r[4], r[5]); ray.dO_dx = V3(r[6], r[7], r[8]); ray.dO_dy = V3(r[9], r[10], r[11]);
+    ray.dD_dx = V3(r[12], r[13], r[14]); ray.dD_dy = V3(r[15], r[16], r[17]);
+    const uint32_t s = (uint32_t)q.level_base[1] + (uint32_t)i;
+    const float4 h0 = q.h0[s]; const int tri = q.h1[s], prim = as_i(h0.w);
+    float * o = out + 27 * (size_t)i;
+    for (int k = 0; k < 27; k++) o[k] = 0.0f;
+    o[1] = h0.x;
+    if (PRIM_KIND(prim) == PRIM_NONE) return;
+    HitFull h; h.material_id = 0;
+    h.point = h.normal = h.dO_dx = h.dO_dy = h.dN_dx = h.dN_dy = V3(0, 0, 0); h.u = h.v = h.ds_dx = h.ds_dy = h.dt_dx = h.dt_dy = 0.0f;
+    if (PRIM_KIND(prim) == PRIM_TRI) rebuild_triangle_hit(sc, PRIM_INDEX(prim), tri, h0.x, h0.y, h0.z, ray, h);
+    else if (PRIM_KIND(prim) == PRIM_SPHERE) rebuild_sphere_hit(sc, sc.spheres[PRIM_INDEX(prim)], h0.x, ray, h);
+    else rebuild_plane_hit(sc, sc.planes[PRIM_INDEX(prim)], h0.x, ray, h);
+    o[0] = 1.0f; o[2] = h.point.x; o[3] = h.point.y; o[4] = h.point.z; o[5] = h.normal.x; o[6] = h.normal.y; o[7] = h.normal.z;
+    o[8] = (float)h.material_id; o[9] = h.u; o[10] = h.v; o[11] = h.ds_dx; o[12] = h.ds_dy; o[13] = h.dt_dx; o[14] = h.dt_dy;
+    o[15] = h.dO_dx.x; o[16] = h.dO_dx.y; o[17] = h.dO_dx.z; o[18] = h.dO_dy.x; o[19] = h.dO_dy.y; o[20] = h.dO_dy.z;
+    o[21] = h.dN_dx.x; o[22] = h.dN_dx.y; o[23] = h.dN_dx.z; o[24] = h.dN_dy.x; o[25] = h.dN_dy.y; o[26] = h.dN_dy.z;
+}
+__global__ void k_debug_fill_shadow(DevQueues q, int nL, const float * od7, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) q.counters->ray_count[0] = (uint32_t)n;
+    if (i >= n) return;
+    const float * r = od7 + 7 * (size_t)i;
+    q.n0[(uint32_t)q.level_base[0] + (uint32_t)i] = make_float4(0.0f, 0.0f, 0.0f, as_f(NF_HIT | NF_LIT));
+    for (int L = 0; L < nL; L++) {
+        const uint32_t s = (uint32_t)q.shadow_base[0] + (uint32_t)L * (uint32_t)q.level_cap[0] + (uint32_t)i;
+        q.s0[s] = make_float4(r[0], r[1], r[2], L == 0 ? r[6] : -1.0f);      // only light 0's segment carries rays; the others are marked culled
+        q.s1[s] = make_float4(r[3], r[4], r[5], 0.0f);
+        q.socc[s] = 0u;
+    }
+}
+
+static int debug_queues(rtx_ctx * c, int n) {
+    if (!c->frame_set) { c->err = "debug trace before rtx_set_frame"; return RTX_ERR_STATE; }
+    if (int bad = validate_references(c)) return bad;
+    const int tiles = (n + 1023) / 1024;
+    if (tiles > 4096) return RTX_ERR_LIMIT;
+    int rc = alloc_queues(c, tiles < 1 ? 1 : tiles);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, (DevCounters *)c->d_counters.p, (uint32_t *)c->d_pk_heads.p, 0u,
+                       (uint32_t)(c->trace_blocks_closest * RTX_TRACE_BLOCK), (uint32_t)(c->trace_blocks_any * RTX_TRACE_BLOCK),
+                       (uint32_t)(c->pk_blocks_closest * (RTX_PK_BLOCK / RTX_WAVE)), (uint32_t)(c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE)), 1);
+    return RTX_OK;
+}
+
+extern "C" int rtx_debug_trace_rays(rtx_ctx * c, const float * rays18, int32_t n, float * hits27, uint32_t flags) {
+    if (!c || !rays18 || !hits27 || n <= 0 || c->cfg.bounces < 1) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    int rc = debug_queues(c, n);
+    if (rc) return rc;
+    float * din = nullptr, * dout = nullptr;
+    HIP_OK(c, hipMalloc(&din, (size_t)n * 72)); HIP_OK(c, hipMalloc(&dout, (size_t)n * 108));
+    HIP_OK(c, hipMemcpy(din, rays18, (size_t)n * 72, hipMemcpyHostToDevice));
+    DevQueues q = c->q; q.first_tile = 0; q.tile_stride = 1; q.tile_count = (n + 1023) / 1024; q.primary_slots = 0; q.tm_packed = nullptr;
+    const DevScene sc = c->scene;
+    hipLaunchKernelGGL(k_debug_fill_rays, dim3((n + 255) / 256), dim3(256), 0, c->stream, q, din, n);
+    if (flags & RTX_RENDER_LANE_TRACE) hipLaunchKernelGGL((k_trace_fast<false>), dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, 1, 1);
+    else {
+        if (flags & RTX_RENDER_PACKET_CLOSEST) q.pk_defer_t0_closest = q.pk_defer_t0;
+        hipLaunchKernelGGL((k_packet<false, false>), dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, 1, 1);
+    }
+    hipLaunchKernelGGL(k_debug_rebuild, dim3((n + 255) / 256), dim3(256), 0, c->stream, sc, q, din, dout, n);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipMemcpy(hits27, dout, (size_t)n * 108, hipMemcpyDeviceToHost));
+    hipFree(din); hipFree(dout);
+    return RTX_OK;
+}
+
+extern "C" int rtx_debug_occluded(rtx_ctx * c, const float * origin_direction_maxdist7, int32_t n, uint32_t * occluded, uint32_t flags) {
+    if (!c || !origin_direction_maxdist7 || !occluded || n <= 0 || c->scene.light_count < 1) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    int rc = debug_queues(c, n);
+    if (rc) return rc;
+    float * din = nullptr;
+    HIP_OK(c, hipMalloc(&din, (size_t)n * 28));
+    HIP_OK(c, hipMemcpy(din, origin_direction_maxdist7, (size_t)n * 28, hipMemcpyHostToDevice));
+    DevQueues q = c->q; q.first_tile = 0; q.tile_stride = 1; q.tile_count = (n + 1023) / 1024; q.primary_slots = n; q.tm_packed = nullptr;
+    const DevScene sc = c->scene;
+    hipLaunchKernelGGL(k_debug_fill_shadow, dim3((n + 255) / 256), dim3(256), 0, c->stream, q, sc.light_count, din, n);
+    if (flags & RTX_RENDER_LANE_TRACE) hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, 0, 0);
+    else hipLaunchKernelGGL((k_packet<true, false>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, 0, 0);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipMemcpy(occluded, q.socc + q.shadow_base[0], (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(din);
+    return RTX_OK;
+}
+
+__global__ void k_debug_light_plot(rtx_point_light pl, rtx_spot_light sl, rtx_directional_light dl, const float * in10, float * out9, const float * rgb, uint32_t * packed, int n_light, int n_plot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_light) {
+        const float * r = in10 + 10 * (size_t)i;
+        const v3 nrm = V3(r[0], r[1], r[2]), tl = V3(r[3], r[4], r[5]), tc = V3(r[6], r[7], r[8]); const float d2 = r[9];
+        const v3 a = vdivs(light_calc(v3p(pl.colour), nrm, tl, tc), d2);                      // PointLight.h:9-11
+        v3 b = V3(0.0f, 0.0f, 0.0f);                                                           // SpotLight.h:17-33, as k_shade evaluates it
+        const float dt = vdot(tl, v3p(sl.negative_direction));
+        if (dt > sl.outer_cutoff) { float f = (dt - sl.outer_cutoff) / (sl.inner_cutoff - sl.outer_cutoff); f = (f > 1.0f) ? 1.0f : f; b = vmuls(vdivs(light_calc(v3p(sl.colour), nrm, tl, tc), d2), f); }
+        const v3 cc = light_calc(v3p(dl.colour), nrm, v3p(dl.negative_direction), tc);         // DirectionalLight.h:9-11
+        float * o = out9 + 9 * (size_t)i;
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = b.x; o[4] = b.y; o[5] = b.z; o[6] = cc.x; o[7] = cc.y; o[8] = cc.z;
+    }
+    if (i < n_plot) packed[i] = plot_pack(V3(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]));     // Window::plot, Window.h:56-65
+}
+
+// Light::calc_lighting of the three light kinds (k_shade's expressions) and Window::plot at caller-supplied inputs
+extern "C" int rtx_debug_light_plot(rtx_ctx * c, const rtx_point_light * pl, const rtx_spot_light * sl, const rtx_directional_light * dl,
+                                    const float * in10, float * out9, int32_t n_light, const float * rgb, uint32_t * packed, int32_t n_plot) {
+    if (!c || !pl || !sl || !dl || n_light < 0 || n_plot < 0 || (n_light && (!in10 || !out9)) || (n_plot && (!rgb || !packed))) return RTX_ERR_INVALID_ARG;
+    hipSetDevice(c->cfg.device);
+    float * din = nullptr, * dout = nullptr, * drgb = nullptr; uint32_t * dpk = nullptr;
+    HIP_OK(c, hipMalloc(&din, (size_t)(n_light + 1) * 40)); HIP_OK(c, hipMalloc(&dout, (size_t)(n_light + 1) * 36));
+    HIP_OK(c, hipMalloc(&drgb, (size_t)(n_plot + 1) * 12)); HIP_OK(c, hipMalloc(&dpk, (size_t)(n_plot + 1) * 4));
+    if (n_light) HIP_OK(c, hipMemcpy(din, in10, (size_t)n_light * 40, hipMemcpyHostToDevice));
+    if (n_plot) HIP_OK(c, hipMemcpy(drgb, rgb, (size_t)n_plot * 12, hipMemcpyHostToDevice));
+    const int n = n_light > n_plot ? n_light : n_plot;
+    hipLaunchKernelGGL(k_debug_light_plot, dim3((n + 255) / 256), dim3(256), 0, c->stream, *pl, *sl, *dl, din, dout, drgb, dpk, n_light, n_plot);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    if (n_light) HIP_OK(c, hipMemcpy(out9, dout, (size_t)n_light * 36, hipMemcpyDeviceToHost));
+    if (n_plot) HIP_OK(c, hipMemcpy(packed, dpk, (size_t)n_plot * 4, hipMemcpyDeviceToHost));
+    hipFree(din); hipFree(dout); hipFree(drgb); hipFree(dpk);
+    return RTX_OK;
+}

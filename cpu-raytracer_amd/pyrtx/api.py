@@ -22,7 +22,7 @@ EXPORTS = ["rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rt
            "rtx_read_framebuffer", "rtx_framebuffer_device_ptrs", "rtx_last_kernel_times", "rtx_enable_kernel_timing",
            "rtx_bind_framebuffer", "rtx_set_stream", "rtx_present", "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample",
            "rtx_group_unique_id", "rtx_group_create", "rtx_group_render", "rtx_group_destroy", "rtx_group_create_local", "rtx_group_render_local",
-           "rtx_debug_group_loopback"]
+           "rtx_debug_group_loopback", "rtx_debug_trace_rays", "rtx_debug_occluded", "rtx_debug_light_plot"]
 
 RTX_RENDER_COUNT_WORK = 1
 RTX_RENDER_SIMPLE_TRACE = 2
@@ -81,6 +81,9 @@ def load_library(path: Optional[str] = None):
     lib.rtx_group_create_local.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
     lib.rtx_group_render_local.argtypes = [C.POINTER(vp), i32, u32]
     lib.rtx_debug_group_loopback.argtypes = [vp, i32, u32]
+    lib.rtx_debug_trace_rays.argtypes = [vp, vp, i32, vp, u32]
+    lib.rtx_debug_occluded.argtypes = [vp, vp, i32, vp, u32]
+    lib.rtx_debug_light_plot.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("rtx_last_error",):
@@ -244,6 +247,25 @@ class Renderer:
         out = np.zeros((in6.shape[0], 3), np.float32)
         self._chk(self.lib.rtx_debug_texture_sample(self.ctx, texture_id, in6.ctypes.data, out.ctypes.data, in6.shape[0]), "rtx_debug_texture_sample")
         return out
+
+    def debug_trace_rays(self, rays18: np.ndarray, flags: int = 0) -> np.ndarray:
+        rays18 = np.ascontiguousarray(rays18, np.float32)
+        out = np.zeros((rays18.shape[0], 27), np.float32)
+        self._chk(self.lib.rtx_debug_trace_rays(self.ctx, rays18.ctypes.data, rays18.shape[0], out.ctypes.data, flags), "rtx_debug_trace_rays")
+        return out
+
+    def debug_occluded(self, origin_direction_maxdist7: np.ndarray, flags: int = 0) -> np.ndarray:
+        r = np.ascontiguousarray(origin_direction_maxdist7, np.float32)
+        out = np.zeros(r.shape[0], np.uint32)
+        self._chk(self.lib.rtx_debug_occluded(self.ctx, r.ctypes.data, r.shape[0], out.ctypes.data, flags), "rtx_debug_occluded")
+        return out
+
+    def debug_light_plot(self, pl, sl, dl, in10: np.ndarray, rgb: np.ndarray):
+        in10 = np.ascontiguousarray(in10, np.float32); rgb = np.ascontiguousarray(rgb, np.float32)
+        out9 = np.zeros((in10.shape[0], 9), np.float32); packed = np.zeros(rgb.shape[0], np.uint32)
+        self._chk(self.lib.rtx_debug_light_plot(self.ctx, pl.ctypes.data, sl.ctypes.data, dl.ctypes.data, in10.ctypes.data, out9.ctypes.data, in10.shape[0],
+                                                rgb.ctypes.data, packed.ctypes.data, rgb.shape[0]), "rtx_debug_light_plot")
+        return out9, packed
 
     def debug_sky_sample(self, dirs: np.ndarray) -> np.ndarray:
         dirs = np.ascontiguousarray(dirs, np.float32)

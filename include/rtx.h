@@ -346,6 +346,16 @@ int rtx_group_render_local(rtx_group ** groups, int32_t n, uint32_t flags);
 int rtx_debug_libm(rtx_ctx * ctx, int32_t fn, const float * a, const float * b, float * out, int32_t n);
 /* Texture::sample (Texture.h:33-49) of an uploaded texture at n inputs (s,t,ds_dx,ds_dy,dt_dx,dt_dy) */
 int rtx_debug_texture_sample(rtx_ctx * ctx, int32_t texture_id, const float * in6, float * out_rgb, int32_t n);
+/* Scene::trace_primitives (Scene.cpp:173-180) of n rays (18 floats each: origin, direction, dO_dx, dO_dy, dD_dx, dD_dy) through the
+ * production closest-hit kernel + the accept-branch rebuild of the shade kernel; out: 27 floats per ray = every RayHit field
+ * (RayHit.h:5-21): hit, distance, point[3], normal[3], material_id, u, v, ds_dx, ds_dy, dt_dx, dt_dy, dO_dx[3], dO_dy[3], dN_dx[3], dN_dy[3]
+ * (zero on a miss except distance).  flags: RTX_RENDER_LANE_TRACE / RTX_RENDER_PACKET_CLOSEST select the kernel.  Needs bounces >= 1. */
+int rtx_debug_trace_rays(rtx_ctx * ctx, const float * rays18, int32_t n, float * hits27, uint32_t flags);
+/* Scene::intersect_primitives (Scene.cpp:182-190) of n rays (7 floats: origin, direction, max distance) through the production shadow-ray kernel */
+int rtx_debug_occluded(rtx_ctx * ctx, const float * origin_direction_maxdist7, int32_t n, uint32_t * occluded, uint32_t flags);
+/* Point / Spot / DirectionalLight::calc_lighting (10 floats in: normal, to_light, to_camera, distance^2; 9 out) and Window::plot */
+int rtx_debug_light_plot(rtx_ctx * ctx, const rtx_point_light * pl, const rtx_spot_light * sl, const rtx_directional_light * dl,
+                         const float * in10, float * out9, int32_t n_light, const float * rgb, uint32_t * packed, int32_t n_plot);
 /* the group path of `world` ranks replayed on this one GPU without RCCL (partition, tile-major writes, frame assembly) */
 int rtx_debug_group_loopback(rtx_ctx * ctx, int32_t world, uint32_t flags);
 /* Sky::sample (Sky.cpp:28-68) of the uploaded sky at n directions */

@@ -68,6 +68,8 @@ def lib():
         _lib.orc_trace_closest.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_void_p]
         _lib.orc_trace_any.restype = C.c_int
         _lib.orc_trace_any.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_void_p, C.c_float]
+        _lib.orc_calc_lighting.restype = None
+        _lib.orc_calc_lighting.argtypes = [C.c_void_p] * 6 + [C.c_float, C.c_void_p]
         _lib.orc_ewa_table.restype = None
         _lib.orc_ewa_table.argtypes = [C.c_void_p]
         _lib.orc_present.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]

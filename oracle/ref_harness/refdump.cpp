@@ -115,6 +115,7 @@ int main(int argc, char ** argv) {
 	std::filesystem::create_directories(outdir);
 
 	int W = 256, H = 256, bounces = NUMBER_OF_BOUNCES, frames = 1; float delta = 0.0f;
+	int unit_n = 0; unsigned unit_seed = 1;
 	bool keep_base = false, drop_base_meshes = false, have_camera = false, have_ambient = false;
 	Vector3 cam_pos; Quaternion cam_rot; Vector3 ambient;
 	std::vector<MeshSpec> meshes;
@@ -165,6 +166,7 @@ int main(int argc, char ** argv) {
 			else if (w[0] == "nolights") { lights_given = true; }
 			else if (w[0] == "matset")  { MatEdit e; e.target = w[1]; e.field = w[2]; e.args.assign(w.begin() + 3, w.end()); edits.push_back(e); }
 			else if (w[0] == "texprobe") { probes.push_back({ w[1], atoi(w[2].c_str()), (unsigned)strtoul(w[3].c_str(), nullptr, 0) }); }
+			else if (w[0] == "unitprobe") { unit_n = atoi(w[1].c_str()); unit_seed = (unsigned)strtoul(w[2].c_str(), nullptr, 0); }
 			else { fprintf(stderr, "unknown script command '%s'\n", w[0].c_str()); return 2; }
 		}
 	}
@@ -499,6 +501,104 @@ int main(int argc, char ** argv) {
 		}
 		char name[64]; snprintf(name, sizeof(name), "texprobe%zu.f32", k);
 		dump(name, io.data(), io.size() * 4);
+	}
+
+	// ---- unit probes: ONE reference function each at seeded inputs ----------------------------------------
+	// unit_rays.f32    per ray 18 inputs (origin, direction, dO_dx, dO_dy, dD_dx, dD_dy) + Scene::trace_primitives' RayHit: hit, distance,
+	//                  point, normal, material_id, u, v, ds_dx, ds_dy, dt_dx, dt_dy, dO_dx, dO_dy, dN_dx, dN_dy (27) + Scene::intersect_primitives
+	//                  for max distances 3 and 1e30 (2): rays aimed at the scene's triangles, spheres and the plane, and some that miss
+	// unit_aabb.f32    AABB::intersect: box min, max, ray origin, inverse direction, max distance (13) + mask (1)
+	// unit_light.f32   Point / Spot / DirectionalLight::calc_lighting: normal, to_light, to_camera, distance_squared (10) + three colours (9)
+	// unit_plot.f32    Window::plot: colour (3) + packed pixel bits (1)
+	if (unit_n > 0) {
+		unsigned s = unit_seed;
+		auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) * (1.0f / 16777216.0f); };
+		auto sym = [&](float a) { return (rnd() * 2.0f - 1.0f) * a; };
+		std::vector<float> io((size_t)unit_n * 47);
+		for (int i = 0; i < unit_n; i++) {
+			float * r = &io[47 * (size_t)i];
+			Vector3 o(sym(6.0f), rnd() * 6.0f, sym(6.0f) - 2.0f);
+			Vector3 target(sym(5.0f), rnd() * 4.0f - 1.5f, sym(5.0f) + 4.0f);
+			Vector3 d = Vector3::normalize(target - o);
+			if (rnd() < 0.1f) d = Vector3(0.0f, rnd() < 0.5f ? -1.0f : 1.0f, 0.0f);        // axis-aligned: zero direction components
+			Ray ray;
+			ray.origin = SIMD_Vector3(o); ray.direction = SIMD_Vector3(d);
+			Vector3 dox(sym(0.01f), sym(0.01f), sym(0.01f)), doy(sym(0.01f), sym(0.01f), sym(0.01f)), ddx(sym(0.002f), sym(0.002f), sym(0.002f)), ddy(sym(0.002f), sym(0.002f), sym(0.002f));
+#if RAY_DIFFERENTIALS_ENABLED
+			ray.dO_dx = SIMD_Vector3(dox); ray.dO_dy = SIMD_Vector3(doy); ray.dD_dx = SIMD_Vector3(ddx); ray.dD_dy = SIMD_Vector3(ddy);
+#endif
+			const Vector3 in[6] = { o, d, dox, doy, ddx, ddy };
+			for (int k = 0; k < 6; k++) { r[3 * k] = in[k].x; r[3 * k + 1] = in[k].y; r[3 * k + 2] = in[k].z; }
+			RayHit h;
+			memset(&h, 0, sizeof(h)); h.hit = SIMD_float(0.0f); h.distance = SIMD_float(INFINITY);      // fields the reference leaves unwritten on a miss read 0 here
+			scene.trace_primitives(ray, h);
+			float * q = r + 18;
+			q[0] = SIMD_float::all_false(h.hit) ? 0.0f : 1.0f; q[1] = h.distance[0];
+			q[2] = h.point.x[0]; q[3] = h.point.y[0]; q[4] = h.point.z[0]; q[5] = h.normal.x[0]; q[6] = h.normal.y[0]; q[7] = h.normal.z[0];
+			q[8] = (float)h.material_id[0]; q[9] = h.u[0]; q[10] = h.v[0];
+#if RAY_DIFFERENTIALS_ENABLED
+			q[11] = h.ds_dx[0]; q[12] = h.ds_dy[0]; q[13] = h.dt_dx[0]; q[14] = h.dt_dy[0];
+			q[15] = h.dO_dx.x[0]; q[16] = h.dO_dx.y[0]; q[17] = h.dO_dx.z[0]; q[18] = h.dO_dy.x[0]; q[19] = h.dO_dy.y[0]; q[20] = h.dO_dy.z[0];
+			q[21] = h.dN_dx.x[0]; q[22] = h.dN_dx.y[0]; q[23] = h.dN_dx.z[0]; q[24] = h.dN_dy.x[0]; q[25] = h.dN_dy.y[0]; q[26] = h.dN_dy.z[0];
+#endif
+			q[27] = SIMD_float::all_false(scene.intersect_primitives(ray, SIMD_float(3.0f))) ? 0.0f : 1.0f;
+			q[28] = SIMD_float::all_false(scene.intersect_primitives(ray, SIMD_float(1e30f))) ? 0.0f : 1.0f;
+		}
+		dump("unit_rays.f32", io.data(), io.size() * 4);
+
+		std::vector<float> ab((size_t)unit_n * 14);
+		for (int i = 0; i < unit_n; i++) {
+			float * r = &ab[14 * (size_t)i];
+			AABB box;
+			Vector3 c(sym(3.0f), sym(3.0f), sym(3.0f)), e(rnd() * 2.0f, rnd() * 2.0f, rnd() * 2.0f);
+			if (rnd() < 0.2f) e.y = 0.0f;                                                  // flat boxes
+			box.min = c - e; box.max = c + e;
+			Vector3 o(sym(5.0f), sym(5.0f), sym(5.0f));
+			if (rnd() < 0.2f) o.x = box.min.x;                                             // origin on a slab plane: 0 * inf when the direction component is 0
+			Vector3 d = Vector3::normalize(Vector3(sym(1.0f), sym(1.0f), sym(1.0f)));
+			if (rnd() < 0.6f) d = Vector3::normalize(c + Vector3(sym(1.2f) * e.x, sym(1.2f) * e.y, sym(1.2f) * e.z) - o);      // aimed at (or just past) the box
+			if (rnd() < 0.3f) d.x = 0.0f;
+			if (rnd() < 0.1f) d.z = -0.0f;
+			Ray ray; ray.origin = SIMD_Vector3(o); ray.direction = SIMD_Vector3(d);
+			SIMD_Vector3 inv = SIMD_Vector3::rcp(ray.direction);
+			const float maxd = rnd() < 0.5f ? INFINITY : rnd() * 8.0f;
+			SIMD_float m = box.intersect(ray, inv, SIMD_float(maxd));
+			r[0] = box.min.x; r[1] = box.min.y; r[2] = box.min.z; r[3] = box.max.x; r[4] = box.max.y; r[5] = box.max.z;
+			r[6] = o.x; r[7] = o.y; r[8] = o.z; r[9] = inv.x[0]; r[10] = inv.y[0]; r[11] = inv.z[0]; r[12] = maxd;
+			r[13] = SIMD_float::all_false(m) ? 0.0f : 1.0f;
+		}
+		dump("unit_aabb.f32", ab.data(), ab.size() * 4);
+
+		std::vector<float> li((size_t)unit_n * 19);
+		PointLight pl(Vector3(20.0f, 30.0f, 26.0f), Vector3(0.0f));
+		SpotLight  sl(Vector3(40.0f, 40.0f, 48.0f), Vector3(0.0f), Vector3::normalize(Vector3(-0.8f, -0.55f, 0.25f)), 50.0f, 70.0f);
+		DirectionalLight dl(Vector3(0.9f, 0.8f, 0.7f), Vector3::normalize(Vector3(0.1f, -1.0f, 0.1f)));
+		for (int i = 0; i < unit_n; i++) {
+			float * r = &li[19 * (size_t)i];
+			Vector3 n = Vector3::normalize(Vector3(sym(1.0f), sym(1.0f), sym(1.0f)));
+			Vector3 tl = Vector3::normalize(Vector3(sym(1.0f), sym(1.0f), sym(1.0f)));
+			if (rnd() < 0.3f) tl = Vector3::normalize(Vector3(0.8f, 0.55f, -0.25f) + Vector3(sym(0.4f), sym(0.4f), sym(0.4f)));      // inside / near the spot cone
+			Vector3 tc = Vector3::normalize(Vector3(sym(1.0f), sym(1.0f), sym(1.0f)));
+			const float d2 = 0.1f + rnd() * 50.0f;
+			r[0] = n.x; r[1] = n.y; r[2] = n.z; r[3] = tl.x; r[4] = tl.y; r[5] = tl.z; r[6] = tc.x; r[7] = tc.y; r[8] = tc.z; r[9] = d2;
+			SIMD_Vector3 a = pl.calc_lighting(SIMD_Vector3(n), SIMD_Vector3(tl), SIMD_Vector3(tc), SIMD_float(d2));
+			SIMD_Vector3 b = sl.calc_lighting(SIMD_Vector3(n), SIMD_Vector3(tl), SIMD_Vector3(tc), SIMD_float(d2));
+			SIMD_Vector3 c = dl.calc_lighting(SIMD_Vector3(n), SIMD_Vector3(tc));
+			r[10] = a.x[0]; r[11] = a.y[0]; r[12] = a.z[0]; r[13] = b.x[0]; r[14] = b.y[0]; r[15] = b.z[0]; r[16] = c.x[0]; r[17] = c.y[0]; r[18] = c.z[0];
+		}
+		dump("unit_light.f32", li.data(), li.size() * 4);
+
+		std::vector<float> pq((size_t)unit_n * 4);
+		Window pw(1, 1, "plot");
+		for (int i = 0; i < unit_n; i++) {
+			float * r = &pq[4 * (size_t)i];
+			const float k = rnd() < 0.2f ? 3.0f : 1.0f;
+			r[0] = sym(0.6f) * k + 0.5f; r[1] = rnd() * k; r[2] = rnd() < 0.1f ? (float)(int)(rnd() * 255.0f) / 255.0f : rnd();
+			pw.plot(0, 0, Vector3(r[0], r[1], r[2]));
+			const unsigned px = pw.frame_buffer[0];
+			memcpy(&r[3], &px, 4);
+		}
+		dump("unit_plot.f32", pq.data(), pq.size() * 4);
 	}
 
 	{

@@ -963,6 +963,15 @@ void orc_trace_closest(const orc_scene * scene, const float r[18], float out[27]
     out[24] = h.dN_dy.x; out[25] = h.dN_dy.y; out[26] = h.dN_dy.z;
 }
 
+/* PointLight / SpotLight / DirectionalLight::calc_lighting at one set of inputs (PointLight.h:9-11, SpotLight.h:17-33, DirectionalLight.h:9-11) */
+void orc_calc_lighting(const rtx_point_light * pl, const rtx_spot_light * sl, const rtx_directional_light * dl,
+                       const float normal[3], const float to_light[3], const float to_camera[3], float distance_squared, float out9[9]) {
+    const v3 a = point_light_calc(v3p(pl->colour), v3p(normal), v3p(to_light), v3p(to_camera), distance_squared);
+    const v3 b = spot_light_calc(sl, v3p(normal), v3p(to_light), v3p(to_camera), distance_squared);
+    const v3 c = light_calc(v3p(dl->colour), v3p(normal), v3p(dl->negative_direction), v3p(to_camera));
+    out9[0] = a.x; out9[1] = a.y; out9[2] = a.z; out9[3] = b.x; out9[4] = b.y; out9[5] = b.z; out9[6] = c.x; out9[7] = c.y; out9[8] = c.z;
+}
+
 int orc_trace_any(const orc_scene * scene, const float origin[3], const float direction[3], float max_distance) {
     counters_t c; memset(&c, 0, sizeof(c));
     return scene_intersect(scene, v3p(origin), v3p(direction), max_distance, &c);

@@ -61,6 +61,8 @@ void     orc_texture_sample(const orc_texture * tex, int32_t texture_mode, int32
                             float s, float t, float ds_dx, float ds_dy, float dt_dx, float dt_dy, float out_rgb[3]);
 void     orc_sky_sample(const float * sky, int32_t size, const float direction[3], float out_rgb[3]);
 uint32_t orc_plot(const float rgb[3]);
+void     orc_calc_lighting(const rtx_point_light * pl, const rtx_spot_light * sl, const rtx_directional_light * dl,
+                           const float normal[3], const float to_light[3], const float to_camera[3], float distance_squared, float out9[9]);
 int32_t  orc_float_to_int(float x);
 void     orc_ewa_table(float out[RTX_EWA_LUT_SIZE]);
 
