@@ -63,7 +63,10 @@ int main(int argc, char ** argv) {
         rtx::Window window(cfg.SCREEN_WIDTH, cfg.SCREEN_HEIGHT);
         rtx::Raytracer raytracer; raytracer.scene = &scene;
         rtx::PerformanceStats stats;
-        raytracer.render_frame(window, stats);
+        if (std::getenv("RTX_FACADE_GROUP")) {    // the multi-GPU route (rtx_group_*_local) with this one GPU as the whole group
+            rtx::RaytracerGroup group; group.init({ &scene });
+            group.render_frame(window, stats);
+        } else raytracer.render_frame(window, stats);
         if (argc > 7 && wants_png(argv[7])) raytracer.draw_quad(window);
         return report(window, stats, argc > 7 ? argv[7] : nullptr);
     } catch (const std::exception & e) { std::fprintf(stderr, "facade_demo: %s\n", e.what()); return 1; }

@@ -316,6 +316,34 @@ struct Raytracer {                  // Raytracer.h:11-18
     }
 };
 
+// Several GPUs of one node driven by ONE process — the shape of the reference's own main loop with its worker pool replaced by GPUs
+// (WorkerThread.cpp:53-65: tiles handed out round robin; include/rtx.h rtx_group_*).  scenes[i] is the same scene built with
+// Config::device = i (every GPU holds the read-only scene); after each scenes[i]->update(delta):
+//     group.render_frame(window, stats);        // every GPU renders its tiles, one RCCL gather, rank 0's frame lands in `window`
+struct RaytracerGroup {
+    std::vector<const Scene *> scenes;
+    std::vector<rtx_group *> groups;
+
+    void init(const std::vector<const Scene *> & per_device_scenes) {
+        scenes = per_device_scenes;
+        std::vector<rtx_ctx *> ctx;
+        for (const Scene * s : scenes) ctx.push_back(s->context());
+        groups.assign(scenes.size(), nullptr);
+        scenes[0]->check(rtx_group_create_local(ctx.data(), (int32_t)ctx.size(), groups.data()), "rtx_group_create_local");
+    }
+    void render_frame(Window & window, PerformanceStats & stats) const {
+        scenes[0]->check(rtx_group_render_local(const_cast<rtx_group **>(groups.data()), (int32_t)groups.size(), 0), "rtx_group_render_local");
+        for (const Scene * s : scenes) {                                  // PerformanceStats: summed over the GPUs like WorkerThread.cpp:131-148 over threads
+            rtx_stats st;
+            s->check(rtx_get_stats(s->context(), &st, nullptr), "rtx_get_stats");
+            stats.num_primary_rays += (long long)st.num_primary_rays; stats.num_shadow_rays += (long long)st.num_shadow_rays;
+            stats.num_reflection_rays += (long long)st.num_reflection_rays; stats.num_refraction_rays += (long long)st.num_refraction_rays;
+        }
+        scenes[0]->check(rtx_read_framebuffer(scenes[0]->context(), nullptr, window.frame_buffer.data()), "rtx_read_framebuffer");    // rank 0 holds the assembled packed frame
+    }
+    ~RaytracerGroup() { for (rtx_group * g : groups) if (g) rtx_group_destroy(g); }
+};
+
 // The numbers of the reference's HUD (Main.cpp:59-95): frame time averaged over the last 100 frames, whole-second fps, MRays/s
 // = per-frame ray counts x fps x 1e-6.  Call frame(delta_seconds, stats) once per frame, like the body of the game loop.
 struct FrameCounters {

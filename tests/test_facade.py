@@ -20,8 +20,10 @@ def fnv1a(packed):
     return f"{h:016x}"
 
 
+@pytest.mark.parametrize("group", [False, True])
 @pytest.mark.parametrize("name", ["cube", "tori16_f1"])
-def test_facade_demo_matches_golden(name, tmp_path):
+def test_facade_demo_matches_golden(name, group, tmp_path):
+    """group: through rtx::RaytracerGroup (rtx_group_create_local / rtx_group_render_local, real RCCL communicator) with one GPU."""
     d, tag, _ = util.GOLDENS[name]
     raw = tmp_path / "scene.rtxs"
     with gzip.open(os.path.join(util.GOLDEN, d, "scene.rtxs.gz"), "rb") as f:
@@ -29,7 +31,8 @@ def test_facade_demo_matches_golden(name, tmp_path):
     sc, g = util.load_golden(name)
     exe = os.path.join(util.REPO, "cpu-raytracer_amd", "host", "facade_demo")
     out = subprocess.run([exe, str(raw), str(sc.width), str(sc.height), str(int(sc.config["bounces"][0])), str(int(sc.config["mip_filter"][0])),
-                          str(int(sc.config["texture_mode"][0]))], capture_output=True, text=True, timeout=120)
+                          str(int(sc.config["texture_mode"][0]))], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, RTX_FACADE_GROUP="1") if group else None)
     assert out.returncode == 0, out.stderr
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert [res["primary"], res["shadow"], res["reflection"], res["refraction"]] == g["stats"].tolist()
