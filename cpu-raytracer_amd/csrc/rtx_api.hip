@@ -16,6 +16,7 @@
 #include <math.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/rtx.h"
 #include "rtx_device.h"
@@ -52,7 +53,7 @@ struct rtx_ctx {
     std::vector<void *> tex_allocs;
     int material_count = 0, sky_size = 0;
     // host copies for validate_references(): every id a kernel will follow is checked on the host before anything is launched
-    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true;
+    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true; bool no_wide = false;
 
     // per-frame state (rtx_set_frame): ONE device block, filled by one asynchronous copy on the context's stream from a ring of pinned
     // staging buffers — the host never waits for the GPU between frames (cfg5: Scene::update + TLAS rebuild every frame)
@@ -119,6 +120,60 @@ static void convert_nodes_pk(const rtx_bvh_node * nodes, int n, std::vector<floa
         out[2 * i]     = make_float4(nodes[i].aabb_min[0], nodes[i].aabb_min[1], nodes[i].aabb_max[0], nodes[i].aabb_max[1]);
         out[2 * i + 1] = make_float4(nodes[i].aabb_min[2], nodes[i].aabb_max[2], l, cnt);
     }
+}
+
+// The shadow-ray packet walk's 4-wide node records (rtx_packet.h, pk_blas_any_asm4).  BottomLevelBVH::intersect (BottomLevelBVH.cpp:398-437)
+// answers "is any triangle hit": the answer does not depend on the order the tree is walked in, and when every child box lies inside its
+// parent's box — componentwise, in the stored floats — it does not depend on the inner nodes either: AABB::intersect (AABB.cpp:38-52) is
+// monotone under nesting in floating point (x -> fl(x - o) and x -> fl(x * inv) are monotone, so t_near(parent) <= t_near(child) and
+// t_far(child) <= t_far(parent) hold exactly, and a ray that passes a child's strict test passes its parent's).  The set of leaves a ray
+// reaches is therefore the set of leaves whose own box it passes together with all ancestors' = (under nesting) the leaves reached through
+// ANY subset of the ancestors.  The record of inner node j lists its grandchildren (children where a child is a leaf): the packet walk
+// tests 4 boxes per fetch and takes half the dependent steps.  Trees that are not nested (or exceed the packed-entry limits) keep the
+// binary walk.  Slots are ordered by the stack need of their subtrees (smallest first, walked first): the worst-case stack occupancy is
+// then the tree's Strahler-like number, returned in *stack_need.
+//   record (128 B, at byte offset 64 * left-child index of j): 4 x { min.x, min.y, max.x, max.y, min.z, max.z, first, leaf count };
+//   first = left-child index of the slot node (inner, count 0) or first triangle (leaf); unused slots hold a point box, which never passes.
+static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, std::vector<float4> & out, int * stack_need) {
+    if (n >= (1 << 24) || tri_count >= (1 << 24)) return false;
+    auto inside = [&](int c, int p) {
+        for (int a = 0; a < 3; a++) if (!(nodes[c].aabb_min[a] >= nodes[p].aabb_min[a] && nodes[c].aabb_max[a] <= nodes[p].aabb_max[a])) return false;
+        return true;
+    };
+    // reachable inner nodes in pre-order (validate_tree has already checked the structure)
+    std::vector<int> order, stack(1, 0);
+    while (!stack.empty()) {
+        const int i = stack.back(); stack.pop_back();
+        const int cnt = nodes[i].count & 0x3fffffff, f = nodes[i].left_or_first;
+        if (cnt > 0) { if (cnt >= 256) return false; continue; }
+        if (f & 1) return false;                                   // records are addressed by left / 2
+        if (!inside(f, i) || !inside(f + 1, i)) return false;      // nesting
+        order.push_back(i); stack.push_back(f); stack.push_back(f + 1);
+    }
+    out.assign((size_t)4 * (n > 0 ? n : 1) + 8, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    std::vector<int> need((size_t)n, 0);                            // packet-stack entries the walk of a subtree can have pending
+    for (size_t k = order.size(); k-- > 0; ) {                      // children before parents
+        const int j = order[k], l = nodes[j].left_or_first;
+        int slot[4], ns = 0;
+        for (int c = l; c <= l + 1; c++) {
+            if ((nodes[c].count & 0x3fffffff) > 0) slot[ns++] = c;
+            else { slot[ns++] = nodes[c].left_or_first; slot[ns++] = nodes[c].left_or_first + 1; }
+        }
+        std::sort(slot, slot + ns, [&](int a, int b) { return need[a] < need[b]; });
+        int nd = 0;
+        for (int s = 0; s < ns; s++) nd = std::max(nd, (ns - 1 - s) + need[slot[s]]);     // slot s is walked with ns-1-s siblings pending
+        need[j] = nd;
+        float4 * rec = &out[(size_t)4 * l];                         // 64 B per unit of `left`, 128 B per record (left is even)
+        for (int s = 0; s < ns; s++) {
+            const rtx_bvh_node & c = nodes[slot[s]];
+            float f, cn; const int cnt = c.count & 0x3fffffff;
+            memcpy(&f, &c.left_or_first, 4); memcpy(&cn, &cnt, 4);
+            rec[2 * s]     = make_float4(c.aabb_min[0], c.aabb_min[1], c.aabb_max[0], c.aabb_max[1]);
+            rec[2 * s + 1] = make_float4(c.aabb_min[2], c.aabb_max[2], f, cn);
+        }
+    }
+    *stack_need = need[0];
+    return true;
 }
 
 extern "C" int rtx_abi_version(void) { return RTX_ABI_VERSION; }
@@ -200,6 +255,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->q.pk_defer_t0 = 8; if (const char * e = getenv("RTX_PK_DEFER")) c->q.pk_defer_t0 = atoi(e);
     c->q.pk_defer_t0_closest = 64; if (const char * e = getenv("RTX_PK_DEFER_CLOSEST")) c->q.pk_defer_t0_closest = atoi(e);
     c->q.pk_order = 1; if (const char * e = getenv("RTX_PK_ORDER")) c->q.pk_order = atoi(e);
+    if (const char * e = getenv("RTX_PK_WIDE")) c->no_wide = atoi(e) == 0;      // RTX_PK_WIDE=0: binary shadow-ray walk for every mesh
     c->q.pk_defer_grow = 3; if (const char * e = getenv("RTX_PK_GROW")) c->q.pk_defer_grow = atoi(e);
     c->q.spill_threads = max_blocks * RTX_TRACE_BLOCK;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast
@@ -273,7 +329,10 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
         th[RTX_TRI_STRIDE * (size_t)i + 2] = make_float4(tri_hot[i].position_edge_2[0], tri_hot[i].position_edge_2[1], tri_hot[i].position_edge_2[2], 0.0f);
     }
     std::vector<float4> ndp; convert_nodes_pk(nodes, node_count, ndp);
-    void * dn = nullptr, * dt = nullptr, * dc = nullptr, * dnp = nullptr;
+    std::vector<float4> nd4; int need4 = 0;
+    const bool wide = !c->no_wide && build_nodes_pk4(nodes, node_count, triangle_count, nd4, &need4) && need4 <= RTX_PK4_MAX_NEED;
+    void * dn = nullptr, * dt = nullptr, * dc = nullptr, * dnp = nullptr, * dn4 = nullptr;
+    if (wide) { HIP_OK(c, hipMalloc(&dn4, nd4.size() * 16)); c->blas_allocs[blas_id].push_back(dn4); HIP_OK(c, hipMemcpy(dn4, nd4.data(), nd4.size() * 16, hipMemcpyHostToDevice)); }
     HIP_OK(c, hipMalloc(&dn, nd.size() * 16)); c->blas_allocs[blas_id].push_back(dn);
     HIP_OK(c, hipMalloc(&dnp, ndp.size() * 16)); c->blas_allocs[blas_id].push_back(dnp);
     HIP_OK(c, hipMemcpy(dnp, ndp.data(), ndp.size() * 16, hipMemcpyHostToDevice));
@@ -292,7 +351,8 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
     c->blas_packet_ok[blas_id] = (leaf_max < 65536 && node_count < (1 << 26) && triangle_count < (1 << 25)) ? 1 : 0;
     DevBlas & B = c->h_blas[blas_id];
     B.nodes = (const float4 *)dn; B.pk_nodes = (const float4 *)dnp; B.tri_hot = (const float4 *)dt; B.tri_cold = (const rtx_triangle_cold *)dc;
-    B.node_count = node_count; B.tri_count = triangle_count; B.material_offset = material_offset; B.pad = 0;
+    B.pk4_nodes = (const float4 *)dn4;
+    B.node_count = node_count; B.tri_count = triangle_count; B.material_offset = material_offset; B.pk4_need = wide ? need4 : -1;
     return upload(c, c->d_blas, c->h_blas.data(), c->h_blas.size() * sizeof(DevBlas));
 }
 
@@ -823,6 +883,12 @@ __global__ void k_debug_sky(const float * sky, int size, const float * dirs, flo
 }
 
 // Sky::sample (Sky.cpp:28-68) at n directions
+extern "C" int rtx_debug_blas_wide(rtx_ctx * c, int32_t blas_id, int32_t * stack_need) {
+    if (!c || !stack_need || blas_id < 0 || (size_t)blas_id >= c->h_blas.size() || !c->h_blas[blas_id].nodes) return RTX_ERR_INVALID_ARG;
+    *stack_need = c->h_blas[blas_id].pk4_nodes ? c->h_blas[blas_id].pk4_need : -1;
+    return RTX_OK;
+}
+
 extern "C" int rtx_debug_sky_sample(rtx_ctx * c, const float * dirs3, float * out3, int32_t n) {
     if (!c || !dirs3 || !out3 || n <= 0) return RTX_ERR_INVALID_ARG;
     hipSetDevice(c->cfg.device);

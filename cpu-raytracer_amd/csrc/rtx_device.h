@@ -45,7 +45,8 @@ struct DevBlas {
     const float4 *            pk_nodes;   // 2 x float4 per node: (min.x, min.y, max.x, max.y) (min.z, max.z, left_or_first, count)   [packet kernels, rtx_packet.h]
     const float4 *            tri_hot;    // RTX_TRI_STRIDE x float4 per triangle: (p0, -) (e1, -) (e2, -) (padding)
     const rtx_triangle_cold * tri_cold;   // reference layout, 64 B
-    int32_t node_count, tri_count, material_offset, pad;
+    const float4 *            pk4_nodes;  // 4-wide records for the shadow-ray packet walk (128 B at 64 * left-child index), or null: tree not nested / too big
+    int32_t node_count, tri_count, material_offset, pk4_need;
 };
 
 struct DevTexture {

@@ -380,6 +380,103 @@ RTX_D void pk_descend(PkWalk & W, int stack_size, int ordered, int thr) {
     W.pk_steps = steps;
 }
 
+// triangles s98 .. s99-1 of W.tris against the lanes of m: triangle_intersect (BottomLevelBVH.cpp:311-346), the triangle in SGPRs
+// (labels PKB_TRI / PKB_NEXT / PKB_POP and the operands belong to the enclosing asm statement; s88 / s89 / s[84:87] are temporaries)
+#define PK_ASM_TRI_LOOP \
+        "PKB_TRI_%=:\n\t"                                                                                                         \
+        "s_lshl_b32 s89, s98, 6\n\t"                                                                                              \
+        "s_load_dwordx8 s[64:71], s[96:97], s89\n\t"                                                                              \
+        "s_add_u32 s89, s89, 32\n\t"                                                                                              \
+        "s_load_dwordx4 s[72:75], s[96:97], s89\n\t"                                                                              \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                                \
+        /* h = cross(d, e2)                                      p0 = s64..66, e1 = s68..70, e2 = s72..74 */                      \
+        "v_mul_f32 %[t0], s74, %[dy]\n\t"                                                                                         \
+        "v_mul_f32 %[t1], s73, %[dz]\n\t"                                                                                         \
+        "v_mul_f32 %[t2], s72, %[dz]\n\t"                                                                                         \
+        "v_mul_f32 %[t3], s74, %[dx]\n\t"                                                                                         \
+        "v_mul_f32 %[t4], s73, %[dx]\n\t"                                                                                         \
+        "v_mul_f32 %[t5], s72, %[dy]\n\t"                                                                                         \
+        "v_sub_f32 v24, %[t0], %[t1]\n\t"                    /* h.x */                                                            \
+        "v_sub_f32 v25, %[t2], %[t3]\n\t"                    /* h.y */                                                            \
+        "v_sub_f32 v26, %[t4], %[t5]\n\t"                    /* h.z */                                                            \
+        /* a = e1.x*h.x + (e1.y*h.y + e1.z*h.z) */                                                                                \
+        "v_mul_f32 %[t0], s69, v25\n\t"                                                                                           \
+        "v_mul_f32 %[t1], s70, v26\n\t"                                                                                           \
+        "v_mul_f32 %[t2], s68, v24\n\t"                                                                                           \
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"                                                                                       \
+        "v_add_f32 %[t9], %[t2], %[t0]\n\t"                  /* a */                                                              \
+        /* f = 1.0f / a, correctly rounded (the expansion hipcc emits for IEEE division with denormals enabled) */                \
+        "v_div_scale_f32 %[t0], s[84:85], %[t9], %[t9], 1.0\n\t"                                                                  \
+        "v_rcp_f32 %[t1], %[t0]\n\t"                                                                                              \
+        "v_div_scale_f32 %[t2], vcc, 1.0, %[t9], 1.0\n\t"                                                                         \
+        /* s = o - p0 (independent work in the shadow of the rcp) */                                                              \
+        "v_subrev_f32 v27, s64, %[ox]\n\t"                                                                                        \
+        "v_fma_f32 %[t3], -%[t0], %[t1], 1.0\n\t"                                                                                 \
+        "v_fmac_f32 %[t1], %[t3], %[t1]\n\t"                                                                                      \
+        "v_mul_f32 %[t4], %[t2], %[t1]\n\t"                                                                                       \
+        "v_fma_f32 %[t5], -%[t0], %[t4], %[t2]\n\t"                                                                               \
+        "v_fmac_f32 %[t4], %[t5], %[t1]\n\t"                                                                                      \
+        "v_fma_f32 %[t0], -%[t0], %[t4], %[t2]\n\t"                                                                               \
+        "v_subrev_f32 v28, s65, %[oy]\n\t"                                                                                        \
+        "v_div_fmas_f32 %[t0], %[t0], %[t1], %[t4]\n\t"                                                                           \
+        "v_subrev_f32 v29, s66, %[oz]\n\t"                                                                                        \
+        "v_div_fixup_f32 %[t8], %[t0], %[t9], 1.0\n\t"       /* f */                                                              \
+        /* u = f * (s.x*h.x + (s.y*h.y + s.z*h.z)) */                                                                             \
+        "v_mul_f32 %[t0], v28, v25\n\t"                                                                                           \
+        "v_mul_f32 %[t1], v29, v26\n\t"                                                                                           \
+        "v_mul_f32 %[t2], v27, v24\n\t"                                                                                           \
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"                                                                                       \
+        "v_add_f32 %[t0], %[t2], %[t0]\n\t"                                                                                       \
+        "v_mul_f32 %[t7], %[t8], %[t0]\n\t"                  /* u */                                                              \
+        "v_cmp_lt_f32 s[84:85], 0, %[t7]\n\t"                /* u > 0 */                                                          \
+        "v_cmp_gt_f32 s[86:87], 1.0, %[t7]\n\t"              /* u < 1 */                                                          \
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"                                                                              \
+        "s_and_b64 s[84:85], s[84:85], %[m]\n\t"                                                                                  \
+        "s_cmp_lg_u64 s[84:85], 0\n\t"                                                                                            \
+        "s_cbranch_scc0 PKB_NEXT_%=\n\t"                     /* no lane of the node passes the u test */                          \
+        /* q = cross(s, e1) */                                                                                                    \
+        "v_mul_f32 %[t0], s70, v28\n\t"                                                                                           \
+        "v_mul_f32 %[t1], s69, v29\n\t"                                                                                           \
+        "v_mul_f32 %[t2], s68, v29\n\t"                                                                                           \
+        "v_mul_f32 %[t3], s70, v27\n\t"                                                                                           \
+        "v_mul_f32 %[t4], s69, v27\n\t"                                                                                           \
+        "v_mul_f32 %[t5], s68, v28\n\t"                                                                                           \
+        "v_sub_f32 v24, %[t0], %[t1]\n\t"                    /* q.x  (h is dead) */                                               \
+        "v_sub_f32 v25, %[t2], %[t3]\n\t"                    /* q.y */                                                            \
+        "v_sub_f32 v26, %[t4], %[t5]\n\t"                    /* q.z */                                                            \
+        /* v = f * (d.x*q.x + (d.y*q.y + d.z*q.z)) */                                                                             \
+        "v_mul_f32 %[t0], %[dy], v25\n\t"                                                                                         \
+        "v_mul_f32 %[t1], %[dz], v26\n\t"                                                                                         \
+        "v_mul_f32 %[t2], %[dx], v24\n\t"                                                                                         \
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"                                                                                       \
+        "v_add_f32 %[t0], %[t2], %[t0]\n\t"                                                                                       \
+        "v_mul_f32 %[t6], %[t8], %[t0]\n\t"                  /* v */                                                              \
+        /* t = f * (e2.x*q.x + (e2.y*q.y + e2.z*q.z)) */                                                                          \
+        "v_mul_f32 %[t0], s73, v25\n\t"                                                                                           \
+        "v_mul_f32 %[t1], s74, v26\n\t"                                                                                           \
+        "v_mul_f32 %[t2], s72, v24\n\t"                                                                                           \
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"                                                                                       \
+        "v_add_f32 %[t0], %[t2], %[t0]\n\t"                                                                                       \
+        "v_mul_f32 %[t5], %[t8], %[t0]\n\t"                  /* t */                                                              \
+        "v_add_f32 %[t4], %[t7], %[t6]\n\t"                  /* u + v */                                                          \
+        "v_cmp_lt_f32 s[86:87], 0, %[t6]\n\t"                /* v > 0 */                                                          \
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"                                                                              \
+        "v_cmp_gt_f32 s[86:87], 1.0, %[t4]\n\t"              /* u + v < 1 */                                                      \
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"                                                                              \
+        "v_cmp_lt_f32 s[86:87], %[eps], %[t5]\n\t"           /* t > EPSILON */                                                    \
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"                                                                              \
+        "v_cmp_lt_f32 s[86:87], %[t5], %[tcur]\n\t"          /* t < max distance */                                               \
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"                                                                              \
+        /* lanes that are hit leave the packet */                                                                                 \
+        "s_andn2_b64 %[alive], %[alive], s[84:85]\n\t"                                                                            \
+        "s_andn2_b64 %[m], %[m], s[84:85]\n\t"                                                                                    \
+        "s_cmp_lg_u64 %[m], 0\n\t"                                                                                                \
+        "s_cbranch_scc0 PKB_POP_%=\n\t"                                                                                           \
+        "PKB_NEXT_%=:\n\t"                                                                                                        \
+        "s_add_i32 s98, s98, 1\n\t"                                                                                               \
+        "s_cmp_lt_i32 s98, s99\n\t"                                                                                               \
+        "s_cbranch_scc1 PKB_TRI_%=\n\t"
+
 // ---- the whole any-hit walk of one BLAS, hand-scheduled ------------------------------------------------------------------------
 // BottomLevelBVH::intersect (BottomLevelBVH.cpp:398-437) for the lanes of W.m, from the node in W.cur_* until the packet stack is back
 // at W.floor_sp or no lane is alive: inner nodes (child-pair fetch, two slab tests, push of the right child), leaves
@@ -487,99 +584,7 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
         "PKB_LEAF_%=:\n\t"
         "s_mov_b32 s98, %[first]\n\t"
         "s_add_i32 s99, %[first], s88\n\t"
-        "PKB_TRI_%=:\n\t"
-        "s_lshl_b32 s89, s98, 6\n\t"
-        "s_load_dwordx8 s[64:71], s[96:97], s89\n\t"
-        "s_add_u32 s89, s89, 32\n\t"
-        "s_load_dwordx4 s[72:75], s[96:97], s89\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        // h = cross(d, e2)                                      p0 = s64..66, e1 = s68..70, e2 = s72..74
-        "v_mul_f32 %[t0], s74, %[dy]\n\t"
-        "v_mul_f32 %[t1], s73, %[dz]\n\t"
-        "v_mul_f32 %[t2], s72, %[dz]\n\t"
-        "v_mul_f32 %[t3], s74, %[dx]\n\t"
-        "v_mul_f32 %[t4], s73, %[dx]\n\t"
-        "v_mul_f32 %[t5], s72, %[dy]\n\t"
-        "v_sub_f32 v24, %[t0], %[t1]\n\t"                    // h.x
-        "v_sub_f32 v25, %[t2], %[t3]\n\t"                    // h.y
-        "v_sub_f32 v26, %[t4], %[t5]\n\t"                    // h.z
-        // a = e1.x*h.x + (e1.y*h.y + e1.z*h.z)
-        "v_mul_f32 %[t0], s69, v25\n\t"
-        "v_mul_f32 %[t1], s70, v26\n\t"
-        "v_mul_f32 %[t2], s68, v24\n\t"
-        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
-        "v_add_f32 %[t9], %[t2], %[t0]\n\t"                  // a
-        // f = 1.0f / a, correctly rounded (the expansion hipcc emits for IEEE division with denormals enabled)
-        "v_div_scale_f32 %[t0], s[84:85], %[t9], %[t9], 1.0\n\t"
-        "v_rcp_f32 %[t1], %[t0]\n\t"
-        "v_div_scale_f32 %[t2], vcc, 1.0, %[t9], 1.0\n\t"
-        // s = o - p0 (independent work in the shadow of the rcp)
-        "v_subrev_f32 v27, s64, %[ox]\n\t"
-        "v_fma_f32 %[t3], -%[t0], %[t1], 1.0\n\t"
-        "v_fmac_f32 %[t1], %[t3], %[t1]\n\t"
-        "v_mul_f32 %[t4], %[t2], %[t1]\n\t"
-        "v_fma_f32 %[t5], -%[t0], %[t4], %[t2]\n\t"
-        "v_fmac_f32 %[t4], %[t5], %[t1]\n\t"
-        "v_fma_f32 %[t0], -%[t0], %[t4], %[t2]\n\t"
-        "v_subrev_f32 v28, s65, %[oy]\n\t"
-        "v_div_fmas_f32 %[t0], %[t0], %[t1], %[t4]\n\t"
-        "v_subrev_f32 v29, s66, %[oz]\n\t"
-        "v_div_fixup_f32 %[t8], %[t0], %[t9], 1.0\n\t"       // f
-        // u = f * (s.x*h.x + (s.y*h.y + s.z*h.z))
-        "v_mul_f32 %[t0], v28, v25\n\t"
-        "v_mul_f32 %[t1], v29, v26\n\t"
-        "v_mul_f32 %[t2], v27, v24\n\t"
-        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
-        "v_add_f32 %[t0], %[t2], %[t0]\n\t"
-        "v_mul_f32 %[t7], %[t8], %[t0]\n\t"                  // u
-        "v_cmp_lt_f32 s[84:85], 0, %[t7]\n\t"                // u > 0
-        "v_cmp_gt_f32 s[86:87], 1.0, %[t7]\n\t"              // u < 1
-        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
-        "s_and_b64 s[84:85], s[84:85], %[m]\n\t"
-        "s_cmp_lg_u64 s[84:85], 0\n\t"
-        "s_cbranch_scc0 PKB_NEXT_%=\n\t"                     // no lane of the node passes the u test
-        // q = cross(s, e1)
-        "v_mul_f32 %[t0], s70, v28\n\t"
-        "v_mul_f32 %[t1], s69, v29\n\t"
-        "v_mul_f32 %[t2], s68, v29\n\t"
-        "v_mul_f32 %[t3], s70, v27\n\t"
-        "v_mul_f32 %[t4], s69, v27\n\t"
-        "v_mul_f32 %[t5], s68, v28\n\t"
-        "v_sub_f32 v24, %[t0], %[t1]\n\t"                    // q.x  (h is dead)
-        "v_sub_f32 v25, %[t2], %[t3]\n\t"                    // q.y
-        "v_sub_f32 v26, %[t4], %[t5]\n\t"                    // q.z
-        // v = f * (d.x*q.x + (d.y*q.y + d.z*q.z))
-        "v_mul_f32 %[t0], %[dy], v25\n\t"
-        "v_mul_f32 %[t1], %[dz], v26\n\t"
-        "v_mul_f32 %[t2], %[dx], v24\n\t"
-        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
-        "v_add_f32 %[t0], %[t2], %[t0]\n\t"
-        "v_mul_f32 %[t6], %[t8], %[t0]\n\t"                  // v
-        // t = f * (e2.x*q.x + (e2.y*q.y + e2.z*q.z))
-        "v_mul_f32 %[t0], s73, v25\n\t"
-        "v_mul_f32 %[t1], s74, v26\n\t"
-        "v_mul_f32 %[t2], s72, v24\n\t"
-        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
-        "v_add_f32 %[t0], %[t2], %[t0]\n\t"
-        "v_mul_f32 %[t5], %[t8], %[t0]\n\t"                  // t
-        "v_add_f32 %[t4], %[t7], %[t6]\n\t"                  // u + v
-        "v_cmp_lt_f32 s[86:87], 0, %[t6]\n\t"                // v > 0
-        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
-        "v_cmp_gt_f32 s[86:87], 1.0, %[t4]\n\t"              // u + v < 1
-        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
-        "v_cmp_lt_f32 s[86:87], %[eps], %[t5]\n\t"           // t > EPSILON
-        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
-        "v_cmp_lt_f32 s[86:87], %[t5], %[tcur]\n\t"          // t < max distance
-        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
-        // lanes that are hit leave the packet
-        "s_andn2_b64 %[alive], %[alive], s[84:85]\n\t"
-        "s_andn2_b64 %[m], %[m], s[84:85]\n\t"
-        "s_cmp_lg_u64 %[m], 0\n\t"
-        "s_cbranch_scc0 PKB_POP_%=\n\t"
-        "PKB_NEXT_%=:\n\t"
-        "s_add_i32 s98, s98, 1\n\t"
-        "s_cmp_lt_i32 s98, s99\n\t"
-        "s_cbranch_scc1 PKB_TRI_%=\n\t"
+        PK_ASM_TRI_LOOP
         // ---------------- pop ----------------
         "PKB_POP_%=:\n\t"
         "s_mov_b64 %[m], 0\n\t"
@@ -615,6 +620,160 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
           "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
     W.depth = depth; W.pk_steps = steps;
     if (maxd + 2 > stack_size || err) W.err = 1;       // reference stack: `depth` pending + 2 pushed at the deepest inner node expanded
+}
+
+// ---- the same walk over the 4-wide records (rtx_api.hip, build_nodes_pk4) ----------------------------------------------------------
+// For meshes whose boxes are nested (every reference-built tree): the record of an inner node lists its grandchildren, so one fetch
+// (2 x s_load_dwordx16) feeds four slab tests and the walk takes about half the dependent steps of the binary one; why skipping the
+// intermediate boxes cannot change an any-hit answer is argued at build_nodes_pk4.  Slot 0 is walked first, the other passing slots are
+// pushed (3, 2, 1: popped in slot order); the host has bounded the stack need of every path, so there is no depth bookkeeping.
+//   stack entry: a = first, b = leaf count; deferred entry: leaf count << 24 | first (counts < 256, offsets < 2^24: checked at upload)
+//   SGPRs: s[48:79] the record (slot k at s[48+8k : 55+8k]) / the triangle, s[80:87] slot masks, s88-s93 temporaries, s[94:97] bases.
+//   Instruction budget per step: 68 VALU (+4 v_writelane per push), 20-45 SALU.
+#define RTX_PK4_MAX_NEED 36          // packet-stack entries a BLAS walk may need (64 lanes hold the stack; the TLAS part keeps the rest)
+#define PK4_ASM_PUSH(K)                                                                                                             \
+        "s_cmp_lg_u64 %[m], 0\n\t"                                                                                                  \
+        "s_cbranch_scc0 PKB_SET" #K "_%=\n\t"                                                                                       \
+        "s_cmp_ge_i32 %[sp], 64\n\t"                                                                                                \
+        "s_cbranch_scc1 PKB_OVER" #K "_%=\n\t"                                                                                      \
+        "s_mov_b32 m0, %[sp]\n\t"                                                                                                   \
+        "s_mov_b64 s[92:93], %[m]\n\t"                                                                                              \
+        "s_add_i32 %[sp], %[sp], 1\n\t"                                                                                             \
+        "v_writelane_b32 %[sta], %[first], m0\n\t"                                                                                  \
+        "v_writelane_b32 %[stb], %[cnt], m0\n\t"                                                                                    \
+        "v_writelane_b32 %[stmlo], s92, m0\n\t"                                                                                     \
+        "v_writelane_b32 %[stmhi], s93, m0\n\t"                                                                                     \
+        "PKB_SET" #K "_%=:\n\t"
+RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds, int defer_t0, int grow_shift) {
+    W.cur_first = rfl(W.cur_first); W.cur_cnt = rfl(W.cur_cnt & 0x3fffffff); W.m = rfl64(W.m); W.alive = rfl64(W.alive); W.sp = rfl(W.sp);
+    int err = 0, steps = rfl(W.pk_steps);
+    const int floor_sp = rfl(W.floor_sp);
+    defer_t0 = rfl(defer_t0); grow_shift = rfl(grow_shift);
+    const float eps = RAY_EPSILON;
+    const unsigned long long nodes = rfl64((unsigned long long)nodes4), tris = rfl64((unsigned long long)W.tris);
+    float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;          // triangle-test temporaries
+    asm volatile(
+        "s_mov_b64 s[94:95], %[nodes]\n\t"
+        "s_mov_b64 s[96:97], %[tris]\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 PKB_POP_%=\n\t"
+        "PKB_DISPATCH_%=:\n\t"
+        "s_add_i32 %[steps], %[steps], 1\n\t"
+        "s_bcnt1_i32_b64 s89, %[m]\n\t"
+        "s_lshr_b32 s90, %[steps], %[gsh]\n\t"
+        "s_add_i32 s90, s90, %[t0d]\n\t"
+        "s_cmp_le_u32 s89, s90\n\t"
+        "s_cbranch_scc1 PKB_DEFER_%=\n\t"
+        "PKB_NODEFER_%=:\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 PKB_LEAF_%=\n\t"
+        // ---------------- inner node: four slots ----------------
+        "s_lshl_b32 s88, %[first], 6\n\t"
+        "s_load_dwordx16 s[48:63], s[94:95], s88\n\t"
+        "s_add_u32 s88, s88, 64\n\t"
+        "s_load_dwordx16 s[64:79], s[94:95], s88\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        PK_ASM_SLAB(48, 49, 50, 51, 52, 53, "s[80:81]")
+        PK_ASM_SLAB(56, 57, 58, 59, 60, 61, "s[82:83]")
+        PK_ASM_SLAB(64, 65, 66, 67, 68, 69, "s[84:85]")
+        PK_ASM_SLAB(72, 73, 74, 75, 76, 77, "s[86:87]")
+        // the lowest passing slot is walked next, the others are pushed
+        "s_mov_b64 %[m], 0\n\t"
+        "s_cmp_lg_u64 s[86:87], 0\n\t"
+        "s_cbranch_scc0 PKB_S2_%=\n\t"
+        "s_mov_b32 %[first], s78\n\t"
+        "s_mov_b32 %[cnt], s79\n\t"
+        "s_mov_b64 %[m], s[86:87]\n\t"
+        "PKB_S2_%=:\n\t"
+        "s_cmp_lg_u64 s[84:85], 0\n\t"
+        "s_cbranch_scc0 PKB_S1_%=\n\t"
+        PK4_ASM_PUSH(2)
+        "s_mov_b32 %[first], s70\n\t"
+        "s_mov_b32 %[cnt], s71\n\t"
+        "s_mov_b64 %[m], s[84:85]\n\t"
+        "PKB_S1_%=:\n\t"
+        "s_cmp_lg_u64 s[82:83], 0\n\t"
+        "s_cbranch_scc0 PKB_S0_%=\n\t"
+        PK4_ASM_PUSH(1)
+        "s_mov_b32 %[first], s62\n\t"
+        "s_mov_b32 %[cnt], s63\n\t"
+        "s_mov_b64 %[m], s[82:83]\n\t"
+        "PKB_S0_%=:\n\t"
+        "s_cmp_lg_u64 s[80:81], 0\n\t"
+        "s_cbranch_scc0 PKB_SDONE_%=\n\t"
+        PK4_ASM_PUSH(0)
+        "s_mov_b32 %[first], s54\n\t"
+        "s_mov_b32 %[cnt], s55\n\t"
+        "s_mov_b64 %[m], s[80:81]\n\t"
+        "PKB_SDONE_%=:\n\t"
+        "s_cmp_lg_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 PKB_DISPATCH_%=\n\t"
+        "s_branch PKB_POP_%=\n\t"
+        "PKB_OVER2_%=:\n\t"
+        "s_mov_b32 %[err], 1\n\t"
+        "s_branch PKB_SET2_%=\n\t"
+        "PKB_OVER1_%=:\n\t"
+        "s_mov_b32 %[err], 1\n\t"
+        "s_branch PKB_SET1_%=\n\t"
+        "PKB_OVER0_%=:\n\t"
+        "s_mov_b32 %[err], 1\n\t"
+        "s_branch PKB_SET0_%=\n\t"
+        // ---------------- defer: push the node on the private stacks of the lanes in m ----------------
+        "PKB_DEFER_%=:\n\t"
+        "v_cmp_le_u32 vcc, 8, %[psp]\n\t"                   // every lane of m needs room on its private stack
+        "s_and_b64 s[84:85], vcc, %[m]\n\t"
+        "s_cmp_lg_u64 s[84:85], 0\n\t"
+        "s_cbranch_scc1 PKB_NODEFER_%=\n\t"
+        "s_lshl_b32 s89, %[cnt], 24\n\t"
+        "s_or_b32 s89, s89, %[first]\n\t"
+        "s_mov_b64 s[84:85], exec\n\t"
+        "s_mov_b64 exec, %[m]\n\t"
+        "v_lshl_add_u32 %[t0], %[psp], 8, %[llds]\n\t"
+        "v_mov_b32 %[t1], s89\n\t"
+        "ds_write_b32 %[t0], %[t1]\n\t"
+        "v_add_u32 %[psp], 1, %[psp]\n\t"
+        "s_mov_b64 exec, s[84:85]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_branch PKB_POP_%=\n\t"
+        // ---------------- leaf: triangles first .. first + count - 1 ----------------
+        "PKB_LEAF_%=:\n\t"
+        "s_mov_b32 s98, %[first]\n\t"
+        "s_add_i32 s99, %[first], %[cnt]\n\t"
+        PK_ASM_TRI_LOOP
+        // ---------------- pop ----------------
+        "PKB_POP_%=:\n\t"
+        "s_mov_b64 %[m], 0\n\t"
+        "s_cmp_eq_u64 %[alive], 0\n\t"
+        "s_cbranch_scc1 PKB_END_%=\n\t"
+        "s_cmp_le_i32 %[sp], %[floor]\n\t"
+        "s_cbranch_scc1 PKB_END_%=\n\t"
+        "s_sub_i32 %[sp], %[sp], 1\n\t"
+        "s_mov_b32 m0, %[sp]\n\t"
+        "v_readlane_b32 s84, %[stmlo], m0\n\t"
+        "v_readlane_b32 s85, %[stmhi], m0\n\t"
+        "v_readlane_b32 %[first], %[sta], m0\n\t"
+        "v_readlane_b32 %[cnt], %[stb], m0\n\t"
+        "s_and_b64 %[m], s[84:85], %[alive]\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 PKB_POP_%=\n\t"
+        "s_branch PKB_DISPATCH_%=\n\t"
+        "PKB_END_%=:\n\t"
+        : [first] "+&s"(W.cur_first), [cnt] "+&s"(W.cur_cnt), [m] "+&s"(W.m), [alive] "+&s"(W.alive), [sp] "+&s"(W.sp),
+          [err] "+&s"(err), [steps] "+&s"(steps),
+          [sta] "+&v"(W.st_a), [stb] "+&v"(W.st_b), [stmlo] "+&v"(W.st_mlo), [stmhi] "+&v"(W.st_mhi), [psp] "+&v"(W.psp),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7),
+          [t8] "=&v"(t8), [t9] "=&v"(t9)
+        : [nodes] "s"(nodes), [tris] "s"(tris), [floor] "s"(floor_sp),
+          [oxy] "v"(W.ray.o_xy), [ozz] "v"(W.ray.o_zz), [ixy] "v"(W.ray.i_xy), [izz] "v"(W.ray.i_zz), [tcur] "v"(W.ray.tcur),
+          [ox] "v"(W.ray.o_xy.x), [oy] "v"(W.ray.o_xy.y), [oz] "v"(W.ray.o_zz.x), [dx] "v"(W.ray.d.x), [dy] "v"(W.ray.d.y), [dz] "v"(W.ray.d.z),
+          [eps] "s"(eps), [t0d] "s"(defer_t0), [gsh] "s"(grow_shift), [llds] "v"(lane_lds)
+        : "vcc", "scc", "m0", "memory",
+          "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
+          "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
+          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
+          "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
+    W.pk_steps = steps;
+    if (err) W.err = 1;
 }
 
 struct PkHybrid { int * stk; float * stk_key; uint32_t lane_lds; int * spill; float * spill_key; int spill_stride; int * fifo; int fifo_stride; int t0, grow; };
@@ -697,6 +856,64 @@ RTX_D void pk_lane_phase_any(PkWalk & W, const int lane, int * const stk, int * 
     if (lane_iters > W.prof[9]) W.prof[9] = lane_iters;       // slot 9: most iterations of one per-lane phase
     if ((unsigned long long)W.pk_steps > W.prof[5]) W.prof[5] = (unsigned long long)W.pk_steps;   // slot 5: most packet steps of one walk
 #endif
+}
+
+// The per-lane phase over the 4-wide records (entries: leaf count << 24 | first, nodes that passed the lane's slab test): one 128-byte
+// gather feeds four slab tests, the lowest passing slot is walked next, the others go to the private stack.
+RTX_D void pk_lane_phase_any4(PkWalk & W, const int lane, int * const stk, int * const spill, const int spill_stride, rtx_gptr nodes4, rtx_gptr tris) {
+    bool live = (W.alive >> lane) & 1ull;
+    int psp = live ? W.psp : 0;
+    const v3 co = V3(W.ray.o_xy.x, W.ray.o_xy.y, W.ray.o_zz.x), cd = W.ray.d;
+    const float tmax = W.ray.tcur;
+    bool have_cur = false; int cur_first = 0, cur_cnt = 0;
+    auto push = [&](int e) {
+        if (psp < RTX_PK_PRIV) stk[psp * RTX_WAVE] = e;
+        else if (psp < RTX_MAX_STACK + 8) spill[(psp - RTX_PK_PRIV) * spill_stride] = e;
+        else { W.err = 1; return; }
+        psp++;
+    };
+    for (;;) {
+        if (__ballot(live && (have_cur || psp > 0)) == 0ull) break;
+        if (live && have_cur && cur_cnt == 0) {
+            const int base = 4 * cur_first;
+            have_cur = false;
+            #pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                const float4 q0 = gld(nodes4, base + 2 * k), q1 = gld(nodes4, base + 2 * k + 1);
+                if (pk_slab<true>(q0, q1, W.ray)) {
+                    if (have_cur) push((int)(((uint32_t)cur_cnt << 24) | (uint32_t)cur_first));
+                    cur_first = as_i(q1.z); cur_cnt = as_i(q1.w); have_cur = true;
+                }
+            }
+        }
+        if (live && have_cur && cur_cnt > 0) {
+            have_cur = false;
+            for (int i = cur_first; i < cur_first + cur_cnt; i++) {
+                const float4 p0 = gld(tris, RTX_TRI_STRIDE * i), e1 = gld(tris, RTX_TRI_STRIDE * i + 1), e2 = gld(tris, RTX_TRI_STRIDE * i + 2);
+                const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
+                const v3 h = vcross(cd, edge_2);
+                const float a = vdot(edge_1, h);
+                const float f = 1.0f / a;
+                const v3 s = vsub(co, V3(p0.x, p0.y, p0.z));
+                const float u = f * vdot(s, h);
+                if (!((u > 0.0f) & (u < 1.0f))) continue;
+                const v3 qq = vcross(s, edge_1);
+                const float v = f * vdot(cd, qq);
+                if (!((v > 0.0f) & ((u + v) < 1.0f))) continue;
+                const float t = f * vdot(edge_2, qq);
+                if (!((t > RAY_EPSILON) & (t < tmax))) continue;
+                live = false; break;
+            }
+        }
+        if (live && !have_cur && psp > 0) {
+            psp--;
+            const int e = (psp < RTX_PK_PRIV) ? stk[psp * RTX_WAVE] : spill[(psp - RTX_PK_PRIV) * spill_stride];
+            cur_first = e & 0x00ffffff; cur_cnt = (int)((uint32_t)e >> 24);
+            have_cur = true;
+        }
+    }
+    W.alive &= __ballot(live);
+    W.psp = 0;
 }
 
 // ---- hybrid closest-hit walk, per-lane phase ----------------------------------------------------------------------------------
@@ -933,9 +1150,15 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
                 // the whole BLAS walk, hand-scheduled (returns with m == 0), then the per-lane phase over what it deferred
                 PK_T0();
                 W.psp = 0;
-                pk_blas_any_asm(W, sc.stack_size, H.lane_lds, H.t0, H.grow);
-                PK_T1(1);
-                if (W.alive != 0ull && __ballot(W.psp > 0) != 0ull) { PK_T0(); pk_lane_phase_any(W, lane, H.stk, H.spill, H.spill_stride, RTX_GPTR(B.nodes), RTX_GPTR(B.tri_hot)); PK_T1(2); }
+                if (B.pk4_nodes) {                                   // nested boxes: the 4-wide records
+                    pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.grow);
+                    PK_T1(1);
+                    if (W.alive != 0ull && __ballot(W.psp > 0) != 0ull) { PK_T0(); pk_lane_phase_any4(W, lane, H.stk, H.spill, H.spill_stride, RTX_GPTR(B.pk4_nodes), RTX_GPTR(B.tri_hot)); PK_T1(2); }
+                } else {
+                    pk_blas_any_asm(W, sc.stack_size, H.lane_lds, H.t0, H.grow);
+                    PK_T1(1);
+                    if (W.alive != 0ull && __ballot(W.psp > 0) != 0ull) { PK_T0(); pk_lane_phase_any(W, lane, H.stk, H.spill, H.spill_stride, RTX_GPTR(B.nodes), RTX_GPTR(B.tri_hot)); PK_T1(2); }
+                }
             }
         } else {
             W.m = pm;

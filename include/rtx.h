@@ -358,6 +358,9 @@ int rtx_debug_light_plot(rtx_ctx * ctx, const rtx_point_light * pl, const rtx_sp
                          const float * in10, float * out9, int32_t n_light, const float * rgb, uint32_t * packed, int32_t n_plot);
 /* the group path of `world` ranks replayed on this one GPU without RCCL (partition, tile-major writes, frame assembly) */
 int rtx_debug_group_loopback(rtx_ctx * ctx, int32_t world, uint32_t flags);
+/* the shadow-ray packet walk of an uploaded mesh: *stack_need = packet-stack entries its 4-wide records can need, or -1 when the mesh keeps
+ * the binary walk (boxes not nested / limits exceeded) */
+int rtx_debug_blas_wide(rtx_ctx * ctx, int32_t blas_id, int32_t * stack_need);
 /* Sky::sample (Sky.cpp:28-68) of the uploaded sky at n directions */
 int rtx_debug_sky_sample(rtx_ctx * ctx, const float * directions_xyz, float * out_rgb, int32_t n);
 

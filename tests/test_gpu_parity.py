@@ -258,3 +258,39 @@ def test_group_render_one_rank_over_rccl(api):
     _, packed = r.framebuffer()
     assert np.array_equal(packed, full["packed"]) and st == full["stats"]
     r.group_destroy()
+
+
+def test_shadow_walk_uses_wide_records_for_reference_trees_and_binary_walk_otherwise(api):
+    """The shadow-ray packet walk takes the 4-wide records (csrc/rtx_api.hip build_nodes_pk4) only for meshes whose child boxes lie
+    inside their parents' boxes — every tree the reference builds.  A tree that violates the nesting keeps the binary walk, and both
+    produce the frame of the oracle, which walks the binary tree node by node as BottomLevelBVH::intersect does."""
+    import copy
+    import orc
+    for name in ["monkey_small", "tori16", "materials_aniso"]:
+        sc, g = util.load_golden(name)
+        r = api.Renderer(sc)
+        needs = [r.debug_blas_wide(i) for i in range(len(sc.blas))]
+        assert all(0 <= n <= 36 for n in needs), (name, needs)
+    sc, g = util.load_golden("monkey_small")
+    sc2 = copy.deepcopy(sc)
+    rng = np.random.default_rng(5)
+    for b in sc2.blas:
+        nodes = b.nodes.copy()
+        # grow the boxes of some non-root nodes beyond their parents' (the tree stays a valid, conservative BVH; only nesting is lost)
+        inner = np.nonzero((nodes["count"] & 0x3FFFFFFF) == 0)[0]
+        picks = rng.choice(inner[inner > 0], size=min(40, len(inner) - 1), replace=False) if len(inner) > 1 else []
+        for i in picks:
+            l = int(nodes["left_or_first"][i])
+            nodes["aabb_min"][l] -= np.float32(0.37); nodes["aabb_max"][l + 1] += np.float32(0.21)
+        b.nodes = nodes
+    r2 = api.Renderer(sc2)
+    assert all(r2.debug_blas_wide(i) == -1 for i in range(len(sc2.blas)))
+    ref = orc.OracleScene(sc2).render(threads=8)
+    for mode in ({}, {"serial": True}, {"lane_trace": True}):
+        out = r2.render(**mode)
+        assert out["stats"] == ref["stats"]
+        assert util.bit_exact(out["rgb"], ref["rgb"]) and np.array_equal(out["packed"], ref["packed"])
+    # the same mesh with its original, nested boxes renders through the wide records and matches the reference's golden frame
+    out = api.Renderer(sc).render()
+    cmp = util.compare_to_golden(out, g)
+    assert cmp["stats_equal"] and cmp["max_abs"] == 0.0 and cmp["packed_mismatch"] == 0
