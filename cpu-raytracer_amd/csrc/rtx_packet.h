@@ -860,7 +860,9 @@ RTX_D void pk_lane_phase_any(PkWalk & W, const int lane, int * const stk, int * 
 
 // The per-lane phase over the 4-wide records (entries: leaf count << 24 | first, nodes that passed the lane's slab test): one 128-byte
 // gather feeds four slab tests, the lowest passing slot is walked next, the others go to the private stack.
-RTX_D void pk_lane_phase_any4(PkWalk & W, const int lane, int * const stk, int * const spill, const int spill_stride, rtx_gptr nodes4, rtx_gptr tris) {
+RTX_D void pk_lane_phase_any4(PkWalk & W, const int lane, const uint32_t lane_lds, int * const spill, const int spill_stride, rtx_gptr nodes4, rtx_gptr tris) {
+    typedef __attribute__((address_space(3))) int lds_int;
+    lds_int * const stk = (lds_int *)(uintptr_t)lane_lds;           // ds_write / ds_read, not flat accesses
     bool live = (W.alive >> lane) & 1ull;
     int psp = live ? W.psp : 0;
     const v3 co = V3(W.ray.o_xy.x, W.ray.o_xy.y, W.ray.o_zz.x), cd = W.ray.d;
@@ -875,16 +877,23 @@ RTX_D void pk_lane_phase_any4(PkWalk & W, const int lane, int * const stk, int *
     for (;;) {
         if (__ballot(live && (have_cur || psp > 0)) == 0ull) break;
         if (live && have_cur && cur_cnt == 0) {
+            // the whole record first (one round trip), the four tests, then the bookkeeping
             const int base = 4 * cur_first;
-            have_cur = false;
-            #pragma unroll
-            for (int k = 3; k >= 0; k--) {
-                const float4 q0 = gld(nodes4, base + 2 * k), q1 = gld(nodes4, base + 2 * k + 1);
-                if (pk_slab<true>(q0, q1, W.ray)) {
-                    if (have_cur) push((int)(((uint32_t)cur_cnt << 24) | (uint32_t)cur_first));
-                    cur_first = as_i(q1.z); cur_cnt = as_i(q1.w); have_cur = true;
-                }
-            }
+            const float4 a0 = gld(nodes4, base), a1 = gld(nodes4, base + 1), b0 = gld(nodes4, base + 2), b1 = gld(nodes4, base + 3);
+            const float4 c0 = gld(nodes4, base + 4), c1 = gld(nodes4, base + 5), d0 = gld(nodes4, base + 6), d1 = gld(nodes4, base + 7);
+            const bool p0 = pk_slab<true>(a0, a1, W.ray), p1 = pk_slab<true>(b0, b1, W.ray), p2 = pk_slab<true>(c0, c1, W.ray), p3 = pk_slab<true>(d0, d1, W.ray);
+            const int e1 = (int)(((uint32_t)as_i(b1.w) << 24) | (uint32_t)as_i(b1.z)), e2 = (int)(((uint32_t)as_i(c1.w) << 24) | (uint32_t)as_i(c1.z));
+            const int e3 = (int)(((uint32_t)as_i(d1.w) << 24) | (uint32_t)as_i(d1.z));
+            // slot k is pushed when it passes and a lower slot passes too (that one is walked first)
+            const bool q3 = p3 & (p0 | p1 | p2), q2 = p2 & (p0 | p1), q1 = p1 & p0;
+            if (psp + 3 <= RTX_PK_PRIV) {
+                if (q3) { stk[psp * RTX_WAVE] = e3; psp++; }
+                if (q2) { stk[psp * RTX_WAVE] = e2; psp++; }
+                if (q1) { stk[psp * RTX_WAVE] = e1; psp++; }
+            } else { if (q3) push(e3); if (q2) push(e2); if (q1) push(e1); }
+            have_cur = p0 | p1 | p2 | p3;
+            cur_first = p0 ? as_i(a1.z) : (p1 ? as_i(b1.z) : (p2 ? as_i(c1.z) : as_i(d1.z)));
+            cur_cnt   = p0 ? as_i(a1.w) : (p1 ? as_i(b1.w) : (p2 ? as_i(c1.w) : as_i(d1.w)));
         }
         if (live && have_cur && cur_cnt > 0) {
             have_cur = false;
@@ -1153,7 +1162,7 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
                 if (B.pk4_nodes) {                                   // nested boxes: the 4-wide records
                     pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.grow);
                     PK_T1(1);
-                    if (W.alive != 0ull && __ballot(W.psp > 0) != 0ull) { PK_T0(); pk_lane_phase_any4(W, lane, H.stk, H.spill, H.spill_stride, RTX_GPTR(B.pk4_nodes), RTX_GPTR(B.tri_hot)); PK_T1(2); }
+                    if (W.alive != 0ull && __ballot(W.psp > 0) != 0ull) { PK_T0(); pk_lane_phase_any4(W, lane, H.lane_lds, H.spill, H.spill_stride, RTX_GPTR(B.pk4_nodes), RTX_GPTR(B.tri_hot)); PK_T1(2); }
                 } else {
                     pk_blas_any_asm(W, sc.stack_size, H.lane_lds, H.t0, H.grow);
                     PK_T1(1);
