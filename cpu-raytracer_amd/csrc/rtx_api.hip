@@ -248,6 +248,8 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_packet<true, false>, RTX_PK_BLOCK, 0);
     c->pk_blocks_any = (c->n_cu * (bpc > 0 ? bpc : 4) + 1) & ~1;
     if (const char * e = getenv("RTX_PK_GRID_SCALE")) { const double f = atof(e); if (f > 0.0) { c->pk_blocks_closest = ((int)(c->pk_blocks_closest * f) + 1) & ~1; c->pk_blocks_any = ((int)(c->pk_blocks_any * f) + 1) & ~1; } }
+    if (const char * e = getenv("RTX_PK_GRID_ANY")) { const double f = atof(e); if (f > 0.0) c->pk_blocks_any = ((int)(c->n_cu * f) + 1) & ~1; }          // blocks per CU (A/B runs)
+    if (const char * e = getenv("RTX_PK_GRID_CLOSEST")) { const double f = atof(e); if (f > 0.0) c->pk_blocks_closest = ((int)(c->n_cu * f) + 1) & ~1; }
     int max_blocks = c->trace_blocks_closest > c->trace_blocks_any ? c->trace_blocks_closest : c->trace_blocks_any;
     if (c->trace_blocks_count > max_blocks) max_blocks = c->trace_blocks_count;
     if (c->pk_blocks_any > max_blocks) max_blocks = c->pk_blocks_any;       // the packet kernels' per-lane phase spills there too
