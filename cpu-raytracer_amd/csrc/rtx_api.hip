@@ -130,8 +130,8 @@ static void convert_nodes_pk(const rtx_bvh_node * nodes, int n, std::vector<floa
 // reaches is therefore the set of leaves whose own box it passes together with all ancestors' = (under nesting) the leaves reached through
 // ANY subset of the ancestors.  The record of inner node j lists its grandchildren (children where a child is a leaf): the packet walk
 // tests 4 boxes per fetch and takes half the dependent steps.  Trees that are not nested (or exceed the packed-entry limits) keep the
-// binary walk.  Slots are ordered by the stack need of their subtrees (smallest first, walked first): the worst-case stack occupancy is
-// then the tree's Strahler-like number, returned in *stack_need.
+// binary walk.  Slot order = visiting order: largest box first (the likeliest occluder), unless that would need too many packet-stack entries
+// at this node — then smallest stack need first, which bounds the occupancy by the tree's Strahler-like number.  *stack_need = the bound.
 //   record (128 B, at byte offset 64 * left-child index of j): 4 x { min.x, min.y, max.x, max.y, min.z, max.z, first, leaf count };
 //   first = left-child index of the slot node (inner, count 0) or first triangle (leaf); unused slots hold a point box, which never passes.
 static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, std::vector<float4> & out, int * stack_need) {
@@ -152,6 +152,11 @@ static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, st
     }
     out.assign((size_t)4 * (n > 0 ? n : 1) + 8, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     std::vector<int> need((size_t)n, 0);                            // packet-stack entries the walk of a subtree can have pending
+    // visiting order = slot order.  For a shadow ray any hit ends the walk, so the likeliest occluder should come first: largest box first
+    // (merged launch 0.652 -> 0.627 ms; by triangle count, density or an RTSAH-style area^2 / cost key: 0.635-0.70).  Where that order would
+    // need more packet-stack entries than the cap, the node falls back to the order that minimises the need (smallest need first).
+    int order_mode = 1; if (const char * e = getenv("RTX_PK4_ORDER")) order_mode = atoi(e);      // 0: always smallest need first (A/B runs)
+    auto area = [&](int i) { const double dx = (double)nodes[i].aabb_max[0] - nodes[i].aabb_min[0], dy = (double)nodes[i].aabb_max[1] - nodes[i].aabb_min[1], dz = (double)nodes[i].aabb_max[2] - nodes[i].aabb_min[2]; const double v = dx * dy + dy * dz + dz * dx; return v == v ? (v < 1e300 ? v : 1e300) : 0.0; };      // a total order even for infinite boxes
     for (size_t k = order.size(); k-- > 0; ) {                      // children before parents
         const int j = order[k], l = nodes[j].left_or_first;
         int slot[4], ns = 0;
@@ -159,9 +164,10 @@ static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, st
             if ((nodes[c].count & 0x3fffffff) > 0) slot[ns++] = c;
             else { slot[ns++] = nodes[c].left_or_first; slot[ns++] = nodes[c].left_or_first + 1; }
         }
-        std::sort(slot, slot + ns, [&](int a, int b) { return need[a] < need[b]; });
-        int nd = 0;
-        for (int s = 0; s < ns; s++) nd = std::max(nd, (ns - 1 - s) + need[slot[s]]);     // slot s is walked with ns-1-s siblings pending
+        auto need_of = [&](const int * sl) { int nd = 0; for (int t = 0; t < ns; t++) nd = std::max(nd, (ns - 1 - t) + need[sl[t]]); return nd; };   // slot t is walked with ns-1-t siblings pending
+        int nd = RTX_PK4_MAX_NEED + 1;
+        if (order_mode != 0) { std::sort(slot, slot + ns, [&](int a, int b) { return area(a) > area(b); }); nd = need_of(slot); }
+        if (nd > RTX_PK4_MAX_NEED - 4) { std::sort(slot, slot + ns, [&](int a, int b) { return need[a] < need[b]; }); nd = need_of(slot); }
         need[j] = nd;
         float4 * rec = &out[(size_t)4 * l];                         // 64 B per unit of `left`, 128 B per record (left is even)
         for (int s = 0; s < ns; s++) {
