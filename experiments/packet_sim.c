@@ -266,3 +266,76 @@ void packet_sim(const Node * nodes, const Tri * tris, const float * cam, int wid
 
 void hybrid_set(int T) { g_defer_T = T; g_hy_packet_steps = g_hy_lane_iters = g_hy_lane_steps = g_hy_packets = g_hy_max_packet_cost = 0; }
 void hybrid_get(double * out) { out[0] = g_hy_packet_steps; out[1] = g_hy_lane_iters; out[2] = g_hy_lane_steps; out[3] = g_hy_packets; out[4] = g_hy_max_packet_cost; }
+
+// ---- order_sim: per-ray any-hit walks of the level-0 shadow rays under different child-order policies (which subtree first?) ----------
+// policy 0 left first, 1 larger box area first, 2 front to back (split axis sign), 3 back to front, 4 smaller t_near first,
+// 5 longer overlap (t_far - t_near) first, 6 larger area x overlap first.   out[policy] = { node-pair steps, triangle tests, rays, occluded }
+static inline int slab_t(const Node * n, const float * o, const float * inv, float maxd, float * tn_out, float * tf_out) {
+    float tn = EPS, tf = maxd;
+    for (int a = 0; a < 3; a++) {
+        float t0 = (n->mn[a] - o[a]) * inv[a], t1 = (n->mx[a] - o[a]) * inv[a];
+        float lo = t0 < t1 ? t0 : t1, hi = t0 > t1 ? t0 : t1;
+        if (lo > tn) tn = lo;
+        if (hi < tf) tf = hi;
+    }
+    *tn_out = tn; *tf_out = tf;
+    return tn < tf;
+}
+static double node_area(const Node * n) { double x = n->mx[0] - n->mn[0], y = n->mx[1] - n->mn[1], z = n->mx[2] - n->mn[2]; return x * y + y * z + z * x; }
+static int order_walk(const Node * nodes, const Tri * tris, const float * o, const float * d, float maxd, int policy, double * out) {
+    float inv[3] = { 1.0f / d[0], 1.0f / d[1], 1.0f / d[2] };
+    int stack[256], sp = 0;
+    float tn, tf;
+    if (!slab_t(&nodes[0], o, inv, maxd, &tn, &tf)) return 0;
+    stack[sp++] = 0;
+    while (sp) {
+        const Node * n = &nodes[stack[--sp]];
+        for (;;) {
+            int cnt = n->count & 0x3fffffff;
+            if (cnt > 0) { for (int i = n->first; i < n->first + cnt; i++) { float t; out[1] += 1; if (tri_test(&tris[i], o, d, maxd, &t)) return 1; } break; }
+            out[0] += 1;
+            int l = n->first, r = n->first + 1;
+            float tnl, tfl, tnr, tfr;
+            int pl = slab_t(&nodes[l], o, inv, maxd, &tnl, &tfl), pr = slab_t(&nodes[r], o, inv, maxd, &tnr, &tfr);
+            int left_first = 1;
+            int axis = (int)((uint32_t)n->count >> 30);
+            switch (policy) {
+                case 1: left_first = node_area(&nodes[l]) >= node_area(&nodes[r]); break;
+                case 2: left_first = axis == 0 ? 1 : d[axis - 1] > 0.0f; break;
+                case 3: left_first = axis == 0 ? 1 : !(d[axis - 1] > 0.0f); break;
+                case 4: left_first = tnl <= tnr; break;
+                case 5: left_first = (tfl - tnl) >= (tfr - tnr); break;
+                case 6: left_first = node_area(&nodes[l]) * (tfl - tnl) >= node_area(&nodes[r]) * (tfr - tnr); break;
+                default: break;
+            }
+            int nn = left_first ? l : r, ff = left_first ? r : l, pn = left_first ? pl : pr, pf = left_first ? pr : pl;
+            if (pn) { if (pf) stack[sp++] = ff; n = &nodes[nn]; } else if (pf) n = &nodes[ff]; else break;
+        }
+    }
+    return 0;
+}
+void order_sim(const Node * nodes, const Tri * tris, const float * cam, int width, int height, const float * lights, int nl, int block_step, double * out /* 7 x 4 */) {
+    memset(out, 0, 7 * 4 * sizeof(double));
+    Stats dummy; memset(&dummy, 0, sizeof(dummy));
+    for (int by = 0; by < height; by += 8 * block_step) for (int bx = 0; bx < width; bx += 8 * block_step) for (int l = 0; l < 64; l++) {
+        int px = bx + (l & 7), py = by + (l >> 3);
+        if (px >= width || py >= height) continue;
+        float v[3], o[3], d[3];
+        for (int a = 0; a < 3; a++) v[a] = cam[3 + a] + (float)px * cam[6 + a] + (float)py * cam[9 + a];
+        float il = 1.0f / sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        for (int a = 0; a < 3; a++) { o[a] = cam[a]; d[a] = v[a] * il; }
+        float best = lane_walk(nodes, tris, o, d, INFINITY, 0, &dummy);
+        if (isinf(best)) continue;
+        for (int L = 0; L < nl; L++) {
+            float so[3], sd[3], smax;
+            for (int a = 0; a < 3; a++) so[a] = o[a] + d[a] * best;
+            if (lights[4 * L] == 0.0f) {
+                float w[3]; for (int a = 0; a < 3; a++) w[a] = lights[4 * L + 1 + a] - so[a];
+                float dist = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+                for (int a = 0; a < 3; a++) sd[a] = w[a] / dist;
+                smax = dist;
+            } else { for (int a = 0; a < 3; a++) sd[a] = lights[4 * L + 1 + a]; smax = INFINITY; }
+            for (int p = 0; p < 7; p++) { out[4 * p + 2] += 1; out[4 * p + 3] += order_walk(nodes, tris, so, sd, smax, p, &out[4 * p]); }
+        }
+    }
+}
