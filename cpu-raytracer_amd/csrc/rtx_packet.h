@@ -1119,6 +1119,7 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
                 pk_lane_phase_closest(W, lane, ordered, H, W.lane_nodes, W.lane_tris);
                 W.pub = W.alive;
             }
+            if (W.sp == 0) return true;                         // nothing left in the TLAS: the world-space ray is not needed again
             W.floor_sp = -1; W.nodes = W.tlas;
             v3 o, d; world(o, d);
             pk_set_ray(W.ray, o, d, vrcp(d));                   // finite for every lane of a packet that started FAST
