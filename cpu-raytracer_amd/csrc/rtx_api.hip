@@ -53,7 +53,7 @@ struct rtx_ctx {
     std::vector<void *> tex_allocs;
     int material_count = 0, sky_size = 0;
     // host copies for validate_references(): every id a kernel will follow is checked on the host before anything is launched
-    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true; bool no_wide = false;
+    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true; int lane_from_level = -1; bool no_wide = false;
 
     // per-frame state (rtx_set_frame): ONE device block, filled by one asynchronous copy on the context's stream from a ring of pinned
     // staging buffers — the host never waits for the GPU between frames (cfg5: Scene::update + TLAS rebuild every frame)
@@ -263,7 +263,8 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->q.pk_defer_t0 = 8; if (const char * e = getenv("RTX_PK_DEFER")) c->q.pk_defer_t0 = atoi(e);
     c->q.pk_defer_t0_closest = 64; if (const char * e = getenv("RTX_PK_DEFER_CLOSEST")) c->q.pk_defer_t0_closest = atoi(e);
     c->q.pk_order = 1; if (const char * e = getenv("RTX_PK_ORDER")) c->q.pk_order = atoi(e);
-    if (const char * e = getenv("RTX_PK_WIDE")) c->no_wide = atoi(e) == 0;      // RTX_PK_WIDE=0: binary shadow-ray walk for every mesh
+    if (const char * e = getenv("RTX_PK_WIDE")) c->no_wide = atoi(e) == 0;
+    if (const char * e = getenv("RTX_LANE_FROM_LEVEL")) c->lane_from_level = atoi(e);      // per-lane kernels from this level on (default: 2 for multi-instance scenes, never otherwise)      // RTX_PK_WIDE=0: binary shadow-ray walk for every mesh
     c->q.pk_defer_grow = 3; if (const char * e = getenv("RTX_PK_GROW")) c->q.pk_defer_grow = atoi(e);
     c->q.spill_threads = max_blocks * RTX_TRACE_BLOCK;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast
@@ -665,16 +666,27 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
             continue;
         }
         // traversal kernels: packet walk (production), per-lane pair fetch (RTX_RENDER_LANE_TRACE), plain pop-and-test (SIMPLE / COUNT_WORK)
+        // Which kernel for which level: a packet's walk of the TLAS costs the UNION of its rays' instances, each entered with its own
+        // transform and per-lane phase, so for the incoherent rays of the deeper levels of a multi-instance scene the per-lane kernels
+        // (refill, per-lane TLAS walk) win by 2.5-4x (cfg5: closest-hit levels 2 / 3 0.43 / 0.45 -> 0.16 / 0.12 ms, shadow rays 0.41 / 0.35 ->
+        // 0.19 / 0.14 ms) while the packet kernels win everywhere else (tools/perlevel3.py).  Both produce the same bits.
+        const int lane_from = c->lane_from_level >= 0 ? c->lane_from_level : (sc.instance_count > 1 ? 2 : RTX_MAX_LEVELS + 1);
         auto launch_closest = [&](int level) {
             launch_timed(c, "k_trace_closest", c->stream, [&] {
                 if (count_work)     hipLaunchKernelGGL((k_trace<false, true>),   dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (simple)    hipLaunchKernelGGL((k_trace<false, false>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else if (lane)      hipLaunchKernelGGL((k_trace_fast<false>),    dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
+                else if (lane || (!pstat && level >= lane_from)) hipLaunchKernelGGL((k_trace_fast<false>),    dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
                 else if (pstat)     hipLaunchKernelGGL((k_packet<false, true>),  dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
                 else                hipLaunchKernelGGL((k_packet<false, false>), dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
             });
         };
         auto launch_any = [&](hipStream_t st, int lo, int hi) {
+            if (!count_work && !simple && !lane && !pstat && hi >= lane_from) {      // levels lo .. lane_from-1 by packets, the rest per lane
+                if (lo < lane_from) launch_timed(c, "k_trace_any", st, [&] { hipLaunchKernelGGL((k_packet<true, false>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, lane_from - 1); });
+                const int l0 = lo > lane_from ? lo : lane_from;
+                launch_timed(c, "k_trace_any", st, [&] { hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, st, sc, q, l0, hi); });
+                return;
+            }
             launch_timed(c, "k_trace_any", st, [&] {
                 if (count_work)     hipLaunchKernelGGL((k_trace<true, true>),   dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, st, sc, q, lo);
                 else if (simple)    hipLaunchKernelGGL((k_trace<true, false>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, st, sc, q, lo);

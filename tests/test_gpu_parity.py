@@ -294,3 +294,16 @@ def test_shadow_walk_uses_wide_records_for_reference_trees_and_binary_walk_other
     out = api.Renderer(sc).render()
     cmp = util.compare_to_golden(out, g)
     assert cmp["stats_equal"] and cmp["max_abs"] == 0.0 and cmp["packed_mismatch"] == 0
+
+
+@pytest.mark.parametrize("lane_from", ["99", "1", "3"])
+@pytest.mark.parametrize("name", ["dynamic", "tori16", "materials_aniso"])
+def test_per_level_kernel_selection_changes_nothing(api, name, lane_from, monkeypatch):
+    """Multi-instance scenes trace levels >= 2 with the per-lane kernels by default (csrc/rtx_api.hip, `lane_from`); whatever the split —
+    packets at every level (99), per-lane from level 1 or 3 — the frame is the reference's, in both launch shapes."""
+    monkeypatch.setenv("RTX_LANE_FROM_LEVEL", lane_from)
+    sc, g = util.load_golden(name)
+    r = api.Renderer(sc)
+    for mode in ({}, {"serial": True}):
+        cmp = util.compare_to_golden(r.render(**mode), g)
+        assert cmp["stats_equal"] and cmp["max_abs"] == 0.0 and cmp["n_diff_pixels"] == 0 and cmp["packed_mismatch"] == 0, (mode, cmp)
