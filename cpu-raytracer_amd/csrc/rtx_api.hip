@@ -670,12 +670,15 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         // transform and per-lane phase, so for the incoherent rays of the deeper levels of a multi-instance scene the per-lane kernels
         // (refill, per-lane TLAS walk) win by 2.5-4x (cfg5: closest-hit levels 2 / 3 0.43 / 0.45 -> 0.16 / 0.12 ms, shadow rays 0.41 / 0.35 ->
         // 0.19 / 0.14 ms) while the packet kernels win everywhere else (tools/perlevel3.py).  Both produce the same bits.
+        // With hundreds of instances the closest-hit reflection rays of level 1 already prefer the per-lane kernel (tools/many_instances.py:
+        // 144 instances 0.52 vs 0.40 ms, 576 instances 0.70 vs 0.39 ms), the shadow rays of level 1 do not (0.48 vs 0.8 ms).
         const int lane_from = c->lane_from_level >= 0 ? c->lane_from_level : (sc.instance_count > 1 ? 2 : RTX_MAX_LEVELS + 1);
+        const int lane_from_closest = c->lane_from_level >= 0 ? c->lane_from_level : (sc.instance_count > 64 ? 1 : lane_from);
         auto launch_closest = [&](int level) {
             launch_timed(c, "k_trace_closest", c->stream, [&] {
                 if (count_work)     hipLaunchKernelGGL((k_trace<false, true>),   dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (simple)    hipLaunchKernelGGL((k_trace<false, false>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
-                else if (lane || (!pstat && level >= lane_from)) hipLaunchKernelGGL((k_trace_fast<false>),    dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
+                else if (lane || (!pstat && level >= lane_from_closest)) hipLaunchKernelGGL((k_trace_fast<false>),    dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
                 else if (pstat)     hipLaunchKernelGGL((k_packet<false, true>),  dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
                 else                hipLaunchKernelGGL((k_packet<false, false>), dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
             });

@@ -1,0 +1,36 @@
+"""Robustness of the per-level kernel choice: N x N instanced meshes (one BLAS) over a reflective plane, 3 lights, depth 3, 1920x1080.
+Per-level traversal times for RTX_LANE_FROM_LEVEL = 99 (packets everywhere), 2 (default rule), 1, 0 (= per-lane kernels everywhere)."""
+import os, subprocess, sys
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if len(sys.argv) > 2 and sys.argv[1] == "child":
+    sys.path.insert(0, os.path.join(REPO, "cpu-raytracer_amd")); sys.path.insert(0, os.path.join(REPO, "tests"))
+    import numpy as np
+    from pyrtx import api, assemble
+    import util
+    n = int(sys.argv[2]); mesh = sys.argv[3]
+    lines = ["size 1920 1080", "bounces 3"]
+    for i in range(n):
+        for j in range(n):
+            lines.append(f"mesh_axis_angle ./Data/{mesh}.obj {(i - n / 2 + 0.5) * 2.6:.3f} 0 {4 + j * 2.6:.3f} 0 1 0 {0.37 * (i * n + j):.3f}")
+    for k in range(n * n):
+        if k % 3 == 0: lines.append(f"matset mesh:{k}:0 reflection 0.6 0.6 0.6")
+    lines += ["plane 0 -1.2 0", "matset plane:0 reflection 0.3 0.3 0.3", "point 30 30 30 0 8 2", "spot 30 30 30 -6 9 0 0.4 -1 0.5 30 70", "dir 0.6 0.6 0.6 0.3 -1 0.2",
+              f"camera_axis_angle 0 {3 + n * 0.4:.2f} {-3 - n * 0.5:.2f} 1 0 0 0.35"]
+    sc = assemble.scene_from_script("\n".join(lines) + "\n", os.path.join(util.GOLDEN, "meshes"), accel="sbvh", mip_filter=1, texture_mode=2)
+    r = api.Renderer(sc)
+    out = r.render(serial=True)
+    for _ in range(2): r.render_async(serial=True)
+    r.synchronize(); r.enable_timing(True)
+    N = 5
+    for _ in range(N): r.render_async(serial=True)
+    r.synchronize(); kt = r.kernel_times(); r.enable_timing(False)
+    g = {}
+    for nme, ms in kt: g.setdefault(nme, []).append(ms)
+    row = {k.replace("k_trace_", ""): [round(float(np.mean(v[i::len(v) // N])), 3) for i in range(len(v) // N)] for k, v in g.items() if "trace" in k}
+    print("n=%d %s lane_from=%s instances=%d rays=%s %s frame %.3f ms crc=%08x" % (n, mesh, os.environ.get("RTX_LANE_FROM_LEVEL"), len(sc.instances), out["stats"], row,
+          sum(sum(v) for v in g.values()) / N, int(np.bitwise_xor.reduce(out["packed"].ravel().astype(np.uint32)))), flush=True)
+else:
+    for spec in sys.argv[1:] or ["4:Monkey", "12:Monkey"]:
+        n, mesh = spec.split(":")
+        for lf in ("-1", "99", "2", "1", "0"):
+            subprocess.run([sys.executable, os.path.abspath(__file__), "child", n, mesh], env=dict(os.environ, RTX_LANE_FROM_LEVEL=lf), timeout=600)
