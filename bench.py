@@ -234,12 +234,16 @@ def main():
         if world > 1 or args.force_gather:
             # multi-GPU path of the C ABI (include/rtx.h rtx_group_*): RCCL is called by librtx_hip.so itself; torch.distributed only
             # carries the 128-byte communicator id from rank 0 to the other ranks (and the barrier / max-over-ranks of the timing contract)
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(api.Renderer.group_unique_id()), dtype=torch.uint8))
-            if world > 1:
-                dist.broadcast(uid, src=0)
-            sl.r.group_create(rank, world, bytes(uid.cpu().numpy().tobytes()))
+            # ONE communicator per rank: the first frame slot creates it, the other frames in flight join it (rtx_group_attach)
+            if k == 0:
+                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(api.Renderer.group_unique_id()), dtype=torch.uint8))
+                if world > 1:
+                    dist.broadcast(uid, src=0)
+                sl.r.group_create(rank, world, bytes(uid.cpu().numpy().tobytes()))
+            else:
+                sl.r.group_attach(slots[0].r)
             sl.gather = True
         slots.append(sl)
     r, fb_rgb, fb_packed, gather = slots[0].r, slots[0].fb_rgb, slots[0].fb_packed, slots[0].gather

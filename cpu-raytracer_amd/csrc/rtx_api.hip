@@ -964,10 +964,15 @@ static RcclApi * rccl() {
     return &api;
 }
 
+// One communicator per rank, shared by every context of that rank that joins it (rtx_group_attach: further frames in flight on the same GPU).
+// With more than one member the gathers are issued on the hub's own exchange stream, in call order: every rank issues them in the same
+// order whatever order its frames finish rendering in, and no two collectives of a rank are ever in flight at once.
+struct GroupHub { rtx_nccl_comm comm = nullptr; hipStream_t xs = nullptr; int refs = 1; int device = 0; };
 struct rtx_group {
     rtx_ctx * ctx = nullptr;
     int rank = 0, world = 1, tiles_total = 0, tiles_per_rank = 0, own_tiles = 0;
-    rtx_nccl_comm comm = nullptr;
+    GroupHub * hub = nullptr;
+    hipEvent_t ev_rendered = nullptr, ev_gathered = nullptr;
     DevBuf send, recv;           // tile-major packed pixels: this rank's tiles; on rank 0 every rank's
 };
 
@@ -1004,10 +1009,27 @@ extern "C" int rtx_group_create(rtx_ctx * c, int32_t rank, int32_t world, const 
     hipSetDevice(c->cfg.device);
     rtx_nccl_id id; memset(&id, 0, sizeof(id));
     if (id128) memcpy(&id, id128, sizeof(id)); else if (r->GetUniqueId(&id) != 0) { delete g; return RTX_ERR_HIP; }
-    const int e = r->CommInitRank(&g->comm, world, id, rank);
-    if (e != 0) { c->err = std::string("ncclCommInitRank: ") + r->GetErrorString(e); delete g; return RTX_ERR_HIP; }
+    g->hub = new GroupHub(); g->hub->device = c->cfg.device;
+    const int e = r->CommInitRank(&g->hub->comm, world, id, rank);
+    if (e != 0) { c->err = std::string("ncclCommInitRank: ") + r->GetErrorString(e); delete g->hub; delete g; return RTX_ERR_HIP; }
     const int rc = group_setup(g);
-    if (rc) { r->CommDestroy(g->comm); delete g; return rc; }
+    if (rc) { r->CommDestroy(g->hub->comm); delete g->hub; delete g; return rc; }
+    *out = g;
+    return RTX_OK;
+}
+
+// A further context of the same process and GPU (another frame in flight) joins `base`'s communicator as the same rank.
+extern "C" int rtx_group_attach(rtx_ctx * c, rtx_group * base, rtx_group ** out) {
+    if (!c || !base || !base->hub || !out || c == base->ctx || c->cfg.device != base->hub->device ||
+        c->cfg.width != base->ctx->cfg.width || c->cfg.height != base->ctx->cfg.height) return RTX_ERR_INVALID_ARG;
+    *out = nullptr;
+    hipSetDevice(c->cfg.device);
+    GroupHub * h = base->hub;
+    if (!h->xs) HIP_OK(c, hipStreamCreateWithFlags(&h->xs, hipStreamNonBlocking));
+    rtx_group * g = new rtx_group();
+    g->ctx = c; g->rank = base->rank; g->world = base->world; g->hub = h; h->refs++;
+    const int rc = group_setup(g);
+    if (rc) { h->refs--; delete g; return rc; }
     *out = g;
     return RTX_OK;
 }
@@ -1023,7 +1045,7 @@ extern "C" int rtx_group_create_local(rtx_ctx ** contexts, int32_t n, rtx_group 
     if (e != 0) { contexts[0]->err = std::string("ncclCommInitAll: ") + r->GetErrorString(e); return RTX_ERR_HIP; }
     for (int i = 0; i < n; i++) {
         rtx_group * g = new rtx_group();
-        g->ctx = contexts[i]; g->rank = i; g->world = n; g->comm = comms[i];
+        g->ctx = contexts[i]; g->rank = i; g->world = n; g->hub = new GroupHub(); g->hub->comm = comms[i]; g->hub->device = devs[i];
         const int rc = group_setup(g);
         if (rc) { delete g; return rc; }
         out_groups[i] = g;
@@ -1041,8 +1063,15 @@ static int group_render_one(rtx_group * g, uint32_t flags, bool render, bool gat
     }
     if (gather) {
         // the one exchange of a frame: every rank's tiles_per_rank * 4 KiB of packed pixels to rank 0, on the stream the frame was rendered on
-        const int e = r->Gather(g->send.p, g->recv.p, (size_t)g->tiles_per_rank * 1024, /*ncclUint32*/ 3, 0, g->comm, c->stream);
+        hipStream_t xs = c->stream;
+        if (g->hub->xs) {                                   // shared communicator: the exchange stream orders this rank's collectives
+            if (!g->ev_rendered) { HIP_OK(c, hipEventCreateWithFlags(&g->ev_rendered, hipEventDisableTiming)); HIP_OK(c, hipEventCreateWithFlags(&g->ev_gathered, hipEventDisableTiming)); }
+            xs = g->hub->xs;
+            HIP_OK(c, hipEventRecord(g->ev_rendered, c->stream)); HIP_OK(c, hipStreamWaitEvent(xs, g->ev_rendered, 0));
+        }
+        const int e = r->Gather(g->send.p, g->recv.p, (size_t)g->tiles_per_rank * 1024, /*ncclUint32*/ 3, 0, g->hub->comm, xs);
         if (e != 0) { c->err = std::string("ncclGather: ") + r->GetErrorString(e); return RTX_ERR_HIP; }
+        if (xs != c->stream) { HIP_OK(c, hipEventRecord(g->ev_gathered, xs)); HIP_OK(c, hipStreamWaitEvent(c->stream, g->ev_gathered, 0)); }
     }
     if (finish && g->rank == 0) {
         const int tcx = (c->cfg.width + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE;
@@ -1077,7 +1106,12 @@ extern "C" int rtx_group_render_local(rtx_group ** groups, int32_t n, uint32_t f
 extern "C" int rtx_group_destroy(rtx_group * g) {
     if (!g) return RTX_ERR_INVALID_ARG;
     if (g->ctx) { hipSetDevice(g->ctx->cfg.device); if (g->ctx->stream) hipStreamSynchronize(g->ctx->stream); }
-    if (g->comm) { RcclApi * r = rccl(); if (r) r->CommDestroy(g->comm); }
+    if (g->hub) {
+        if (g->hub->xs) hipStreamSynchronize(g->hub->xs);
+        if (--g->hub->refs == 0) { RcclApi * r = rccl(); if (r && g->hub->comm) r->CommDestroy(g->hub->comm); if (g->hub->xs) hipStreamDestroy(g->hub->xs); delete g->hub; }
+    }
+    if (g->ev_rendered) hipEventDestroy(g->ev_rendered);
+    if (g->ev_gathered) hipEventDestroy(g->ev_gathered);
     if (g->send.p) hipFree(g->send.p);
     if (g->recv.p) hipFree(g->recv.p);
     delete g;

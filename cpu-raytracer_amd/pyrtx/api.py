@@ -21,7 +21,7 @@ EXPORTS = ["rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rt
            "rtx_upload_texture", "rtx_upload_sky", "rtx_set_frame", "rtx_render_tiles", "rtx_synchronize", "rtx_get_stats",
            "rtx_read_framebuffer", "rtx_framebuffer_device_ptrs", "rtx_last_kernel_times", "rtx_enable_kernel_timing",
            "rtx_bind_framebuffer", "rtx_set_stream", "rtx_present", "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample", "rtx_debug_blas_wide",
-           "rtx_group_unique_id", "rtx_group_create", "rtx_group_render", "rtx_group_destroy", "rtx_group_create_local", "rtx_group_render_local",
+           "rtx_group_unique_id", "rtx_group_create", "rtx_group_render", "rtx_group_destroy", "rtx_group_attach", "rtx_group_create_local", "rtx_group_render_local",
            "rtx_debug_group_loopback", "rtx_debug_trace_rays", "rtx_debug_occluded", "rtx_debug_light_plot"]
 
 RTX_RENDER_COUNT_WORK = 1
@@ -77,6 +77,7 @@ def load_library(path: Optional[str] = None):
     lib.rtx_debug_blas_wide.argtypes = [vp, i32, vp]
     lib.rtx_group_unique_id.argtypes = [vp]
     lib.rtx_group_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    lib.rtx_group_attach.argtypes = [vp, vp, C.POINTER(vp)]
     lib.rtx_group_render.argtypes = [vp, u32]
     lib.rtx_group_destroy.argtypes = [vp]
     lib.rtx_group_create_local.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
@@ -223,6 +224,11 @@ class Renderer:
     def group_create(self, rank: int, world: int, unique_id: Optional[bytes] = None):
         self.group = C.c_void_p()
         self._chk(self.lib.rtx_group_create(self.ctx, rank, world, unique_id, C.byref(self.group)), "rtx_group_create")
+
+    def group_attach(self, base: "Renderer"):
+        """Another frame in flight on the same GPU: joins `base`'s communicator as the same rank (rtx_group_attach)."""
+        self.group = C.c_void_p()
+        self._chk(self.lib.rtx_group_attach(self.ctx, base.group, C.byref(self.group)), "rtx_group_attach")
 
     def group_render(self, cull_dead_shadow_rays: bool = False, lane_trace: bool = False):
         flags = (RTX_RENDER_CULL_DEAD_SHADOW_RAYS if cull_dead_shadow_rays else 0) | (RTX_RENDER_LANE_TRACE if lane_trace else 0)

@@ -335,6 +335,11 @@ int rtx_group_create(rtx_ctx * ctx, int32_t rank, int32_t world, const void * id
  * flags as rtx_render_tiles (RTX_RENDER_SERIAL is implied).  rtx_get_stats afterwards covers this rank's tiles. */
 int rtx_group_render(rtx_group * group, uint32_t flags);
 int rtx_group_destroy(rtx_group * group);
+/* several frames in flight on one GPU (one context each, as bench.py runs them): the further contexts JOIN the first one's communicator
+ * as the same rank instead of opening their own.  The gathers of all members are then issued on one exchange stream per rank in call
+ * order (events tie them to the frames' own streams), so every rank issues its collectives in the same order whatever order its frames
+ * finish in, and a rank never has two collectives in flight.  Every rank must call rtx_group_render on its members in the same order. */
+int rtx_group_attach(rtx_ctx * ctx, rtx_group * base, rtx_group ** out_group);
 /* one process driving n GPUs, contexts[i] on its own device = rank i (ncclCommInitAll); render issues all ranks' calls */
 int rtx_group_create_local(rtx_ctx ** contexts, int32_t n, rtx_group ** out_groups);
 int rtx_group_render_local(rtx_group ** groups, int32_t n, uint32_t flags);

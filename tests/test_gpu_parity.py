@@ -260,6 +260,26 @@ def test_group_render_one_rank_over_rccl(api):
     r.group_destroy()
 
 
+def test_group_frames_in_flight_share_one_communicator(api):
+    """bench.py's N > 1 shape on one GPU: three contexts (frames in flight) of one rank, the second and third JOIN the first one's
+    communicator (rtx_group_attach); their gathers go through the rank's exchange stream in call order.  Different frames per context
+    (cfg5 frames 0 and 1), several rounds without host synchronisation in between; each assembled frame must be the single-GPU frame."""
+    scenes = [util.load_golden(n)[0] for n in ("tori16", "tori16_f1", "tori16")]
+    full = [api.Renderer(s).render() for s in scenes]
+    rs = [api.Renderer(s) for s in scenes]
+    rs[0].group_create(0, 1, api.Renderer.group_unique_id())
+    rs[1].group_attach(rs[0]); rs[2].group_attach(rs[0])
+    for _ in range(4):
+        for r in rs:
+            r.group_render()
+    for r, f in zip(rs, full):
+        st, _ = r.stats()
+        _, packed = r.framebuffer()
+        assert np.array_equal(packed, f["packed"]) and st == f["stats"]
+    for r in (rs[1], rs[0], rs[2]):               # any destruction order: the communicator goes with its last member
+        r.group_destroy()
+
+
 def test_shadow_walk_uses_wide_records_for_reference_trees_and_binary_walk_otherwise(api):
     """The shadow-ray packet walk takes the 4-wide records (csrc/rtx_api.hip build_nodes_pk4) only for meshes whose child boxes lie
     inside their parents' boxes — every tree the reference builds.  A tree that violates the nesting keeps the binary walk, and both
