@@ -261,6 +261,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     if (c->pk_blocks_any > max_blocks) max_blocks = c->pk_blocks_any;       // the packet kernels' per-lane phase spills there too
     if (c->pk_blocks_closest > max_blocks) max_blocks = c->pk_blocks_closest;
     c->q.pk_defer_t0 = 8; if (const char * e = getenv("RTX_PK_DEFER")) c->q.pk_defer_t0 = atoi(e);
+    c->q.pk_defer_leaf = c->q.pk_defer_t0 / 2; if (const char * e = getenv("RTX_PK_DEFER_LEAF")) c->q.pk_defer_leaf = atoi(e);
     c->q.pk_defer_t0_closest = 64; if (const char * e = getenv("RTX_PK_DEFER_CLOSEST")) c->q.pk_defer_t0_closest = atoi(e);
     c->q.pk_order = 1; if (const char * e = getenv("RTX_PK_ORDER")) c->q.pk_order = atoi(e);
     if (const char * e = getenv("RTX_PK_WIDE")) c->no_wide = atoi(e) == 0;

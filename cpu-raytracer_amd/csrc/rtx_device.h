@@ -137,6 +137,8 @@ struct DevQueues {
     int32_t       pk_defer_grow;  // ... threshold = pk_defer_t0 + (steps of this packet walk >> pk_defer_grow)
     int32_t       pk_defer_t0_closest;   // the same threshold for closest-hit packets (64 = every lane walks its ray privately from the BLAS root)
     int32_t       pk_defer_t0;    // hybrid any-hit walk: nodes wanted by at most this many lanes (+ walk length / 8) go to the lanes' private stacks
+    int32_t       pk_defer_leaf;  // the same for leaves (a leaf costs the packet one triangle test per triangle)
+    int32_t       pk_pad0;
     DevCounters * counters;
     uint32_t *    stats_partial;  // [level][k_shade block][4]: per-block ray tallies, summed by k_resolve(level 0) (no atomics at the end of k_shade)
     int32_t       shade_blocks;

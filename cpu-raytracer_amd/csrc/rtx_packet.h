@@ -644,11 +644,11 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
         "v_writelane_b32 %[stmlo], s92, m0\n\t"                                                                                     \
         "v_writelane_b32 %[stmhi], s93, m0\n\t"                                                                                     \
         "PKB_SET" #K "_%=:\n\t"
-RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds, int defer_t0, int grow_shift) {
+RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds, int defer_t0, int defer_leaf, int grow_shift) {
     W.cur_first = rfl(W.cur_first); W.cur_cnt = rfl(W.cur_cnt & 0x3fffffff); W.m = rfl64(W.m); W.alive = rfl64(W.alive); W.sp = rfl(W.sp);
     int err = 0, steps = rfl(W.pk_steps);
     const int floor_sp = rfl(W.floor_sp);
-    defer_t0 = rfl(defer_t0); grow_shift = rfl(grow_shift);
+    defer_t0 = rfl(defer_t0); defer_leaf = rfl(defer_leaf); grow_shift = rfl(grow_shift);
     const float eps = RAY_EPSILON;
     const unsigned long long nodes = rfl64((unsigned long long)nodes4), tris = rfl64((unsigned long long)W.tris);
     float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;          // triangle-test temporaries
@@ -661,7 +661,9 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
         "s_add_i32 %[steps], %[steps], 1\n\t"
         "s_bcnt1_i32_b64 s89, %[m]\n\t"
         "s_lshr_b32 s90, %[steps], %[gsh]\n\t"
-        "s_add_i32 s90, s90, %[t0d]\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"                       // a leaf costs the packet a triangle test per triangle: its own threshold
+        "s_cselect_b32 s91, %[tld], %[t0d]\n\t"
+        "s_add_i32 s90, s90, s91\n\t"
         "s_cmp_le_u32 s89, s90\n\t"
         "s_cbranch_scc1 PKB_DEFER_%=\n\t"
         "PKB_NODEFER_%=:\n\t"
@@ -766,7 +768,7 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
         : [nodes] "s"(nodes), [tris] "s"(tris), [floor] "s"(floor_sp),
           [oxy] "v"(W.ray.o_xy), [ozz] "v"(W.ray.o_zz), [ixy] "v"(W.ray.i_xy), [izz] "v"(W.ray.i_zz), [tcur] "v"(W.ray.tcur),
           [ox] "v"(W.ray.o_xy.x), [oy] "v"(W.ray.o_xy.y), [oz] "v"(W.ray.o_zz.x), [dx] "v"(W.ray.d.x), [dy] "v"(W.ray.d.y), [dz] "v"(W.ray.d.z),
-          [eps] "s"(eps), [t0d] "s"(defer_t0), [gsh] "s"(grow_shift), [llds] "v"(lane_lds)
+          [eps] "s"(eps), [t0d] "s"(defer_t0), [tld] "s"(defer_leaf), [gsh] "s"(grow_shift), [llds] "v"(lane_lds)
         : "vcc", "scc", "m0", "memory",
           "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
           "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
@@ -776,7 +778,7 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
     if (err) W.err = 1;
 }
 
-struct PkHybrid { int * stk; float * stk_key; uint32_t lane_lds; int * spill; float * spill_key; int spill_stride; int * fifo; int fifo_stride; int t0, grow; };
+struct PkHybrid { int * stk; float * stk_key; uint32_t lane_lds; int * spill; float * spill_key; int spill_stride; int * fifo; int fifo_stride; int t0, t_leaf, grow; };
 
 // ---- hybrid any-hit walk, per-lane phase -----------------------------------------------------------------------------------------
 // Walks the subtrees the packet walk handed to the lanes' private stacks (entries are nodes that already passed the lane's slab test,
@@ -1161,7 +1163,7 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
                 PK_T0();
                 W.psp = 0;
                 if (B.pk4_nodes) {                                   // nested boxes: the 4-wide records
-                    pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.grow);
+                    pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.t_leaf, H.grow);
                     PK_T1(1);
                     if (W.alive != 0ull && __ballot(W.psp > 0) != 0ull) { PK_T0(); pk_lane_phase_any4(W, lane, H.lane_lds, H.spill, H.spill_stride, RTX_GPTR(B.pk4_nodes), RTX_GPTR(B.tri_hot)); PK_T1(2); }
                 } else {
@@ -1203,7 +1205,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
         H.spill_key = (float *)(q.spill + region) + gt;
         H.fifo = q.pk_fifo + gt; H.fifo_stride = q.spill_threads;
     }
-    H.t0 = ANY ? q.pk_defer_t0 : q.pk_defer_t0_closest; H.grow = q.pk_defer_grow;
+    H.t0 = ANY ? q.pk_defer_t0 : q.pk_defer_t0_closest; H.t_leaf = q.pk_defer_leaf; H.grow = q.pk_defer_grow;
     const uint32_t gwave  = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
     const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE);
 

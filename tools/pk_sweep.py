@@ -23,7 +23,8 @@ else:
     # arguments: T0:grow[:gridscale[:libvariant]] ...
     for spec in sys.argv[1:] or ["8:3"]:
         f = spec.split(":")
-        env = dict(os.environ, RTX_PK_DEFER=f[0], RTX_PK_GROW=f[1] if len(f) > 1 else "3")
+        env = dict(os.environ, RTX_PK_DEFER=f[0].split("L")[0], RTX_PK_GROW=f[1] if len(f) > 1 else "3")
+        if "L" in f[0]: env["RTX_PK_DEFER_LEAF"] = f[0].split("L")[1]
         if len(f) > 2 and f[2]: env["RTX_PK_GRID_SCALE"] = f[2]
         if len(f) > 3 and f[3]: env["RTX_HIP_LIB"] = os.path.join(HERE, "..", "cpu-raytracer_amd", "csrc", "librtx_hip_%s.so" % f[3])
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, timeout=300)
