@@ -156,3 +156,27 @@ def test_cyclic_node_arrays_are_refused(api):
         sc.tlas_nodes["left_or_first"][0] = 0
         with pytest.raises(api.RtxError):
             api.Renderer(sc)
+
+
+@pytest.mark.parametrize("k", [1, 2, 12])
+def test_single_leaf_mesh(api, k):
+    """A mesh whose BVH is one leaf (the root IS the leaf, node_count 1): the packet walkers enter their leaf path straight from the
+    instance entry, the 4-wide records are empty.  Frame == oracle in every launch shape."""
+    import copy
+    import orc
+    sc, _ = util.load_golden("cube")
+    sc = copy.deepcopy(sc)
+    b = sc.blas[0]
+    hot = b.tri_hot[:k].copy(); cold = b.tri_cold[:k].copy()
+    pts = np.concatenate([hot["position_0"], hot["position_0"] + hot["position_edge_1"], hot["position_0"] + hot["position_edge_2"]]).astype(np.float32)
+    nodes = np.zeros(1, util.sio.BVH_NODE)
+    nodes["aabb_min"][0] = pts.min(axis=0); nodes["aabb_max"][0] = pts.max(axis=0)
+    nodes["left_or_first"][0] = 0; nodes["count"][0] = k
+    b.nodes = nodes; b.tri_hot = hot; b.tri_cold = cold
+    ref = orc.OracleScene(sc).render(threads=4)
+    r = api.Renderer(sc)
+    assert r.debug_blas_wide(0) == 0
+    for mode in ({}, {"serial": True}, {"lane_trace": True}, {"packet_closest": True}):
+        out = r.render(**mode)
+        assert out["stats"] == ref["stats"], mode
+        assert util.bit_exact(out["rgb"], ref["rgb"]) and np.array_equal(out["packed"], ref["packed"]), mode
