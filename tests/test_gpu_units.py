@@ -158,13 +158,14 @@ def test_cyclic_node_arrays_are_refused(api):
             api.Renderer(sc)
 
 
-@pytest.mark.parametrize("k", [1, 2, 12])
-def test_single_leaf_mesh(api, k):
+@pytest.mark.parametrize("name,k", [("cube", 1), ("cube", 2), ("cube", 12), ("monkey_small", 300)])
+def test_single_leaf_mesh(api, name, k):
     """A mesh whose BVH is one leaf (the root IS the leaf, node_count 1): the packet walkers enter their leaf path straight from the
-    instance entry, the 4-wide records are empty.  Frame == oracle in every launch shape."""
+    instance entry, the 4-wide records are empty; a leaf of 300 triangles exceeds their packed entries, so that mesh keeps the binary
+    walk.  Frame == oracle in every launch shape."""
     import copy
     import orc
-    sc, _ = util.load_golden("cube")
+    sc, _ = util.load_golden(name)
     sc = copy.deepcopy(sc)
     b = sc.blas[0]
     hot = b.tri_hot[:k].copy(); cold = b.tri_cold[:k].copy()
@@ -175,7 +176,7 @@ def test_single_leaf_mesh(api, k):
     b.nodes = nodes; b.tri_hot = hot; b.tri_cold = cold
     ref = orc.OracleScene(sc).render(threads=4)
     r = api.Renderer(sc)
-    assert r.debug_blas_wide(0) == 0
+    assert r.debug_blas_wide(0) == (0 if k < 256 else -1)
     for mode in ({}, {"serial": True}, {"lane_trace": True}, {"packet_closest": True}):
         out = r.render(**mode)
         assert out["stats"] == ref["stats"], mode
