@@ -388,6 +388,22 @@ def main():
                     roof["other"][k] = {"units_per_launch": int(u), "avg_launch_ms": round(kern[k]["avg_ms"], 5), "frac": round(u / (kern[k]["avg_ms"] * 1e-3) * 1e-9 / slab_peak, 4)}
                     if serial_times and _group(serial_times).get(k):
                         roof["other"][k]["frac_one_frame_at_a_time"] = round(u / (float(np.mean(_group(serial_times)[k])) * 1e-3) * 1e-9 / slab_peak, 4)
+        # the closest-hit launches walk per lane: what binds them is the rate at which the vector memory path serves divergent 64-byte
+        # records (experiments/gather_occupancy.hip), so they get that view too: records = child pairs fetched (half the nodes tested)
+        # + triangles tested + instances entered, per frame, over the closest-hit time of one frame rendered alone
+        gfiles = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_gather_occupancy.txt")))
+        if gfiles and serial_times and _group(serial_times).get("k_trace_closest") and roof.get("other", {}).get("k_trace_closest") is not None:
+            ceil = None
+            for line in open(gfiles[-1]):
+                f = line.split()
+                if len(f) > 8 and f[0] == "table" and f[1] == "32" and f[4].rstrip(":") == "4":
+                    ceil = float(f[7])
+            recs = work["blas_nodes_closest"] / 2 + work["tri_tests_closest"] + work["instances_closest"]
+            t = float(np.sum(_group(serial_times)["k_trace_closest"])) / max(len(_group(serial_times)["k_trace_closest"]) / levels, 1) * 1e-3
+            if ceil:
+                roof["other"]["k_trace_closest"]["gather"] = {"bound": "divergent 64-byte gathers (vector memory path)", "records_per_frame": int(recs),
+                                                              "G_records_per_s": round(recs / t * 1e-9, 1), "ceiling_G_records_per_s": ceil,
+                                                              "frac": round(recs / t * 1e-9 / ceil, 3), "ceiling_source": os.path.relpath(gfiles[-1], REPO)}
         roof["hbm"] = {"algorithmic_bytes_per_launch": int(bytes_frame / max(launches_per_frame, 1)),
                        "algorithmic_GBps": None if achieved_gbps is None else round(achieved_gbps, 1), "peak_GBps": 8000.0,
                        "traffic_bytes_per_launch": traffic, "traffic_source": traffic_src,

@@ -7,6 +7,7 @@ O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 # PMC traffic first: bench.py quotes the newest profiles/r*_hbm_traffic.json as roofline.traffic
 bash tools/hbm_traffic.sh $TAG > /dev/null 2>&1 && cp gpurun_out/hbm_traffic_$TAG.json $O/hbm_traffic.json && cp $O/hbm_traffic.json profiles/${TAG}_hbm_traffic.json
+[ -x experiments/gather_occupancy ] && experiments/gather_occupancy > $O/gather_occupancy.txt 2>&1 && cp $O/gather_occupancy.txt profiles/${TAG}_gather_occupancy.txt
 python3 bench.py > $O/bench_atrium.json 2> $O/bench_atrium.err
 bash tools/roofline_peak.sh > /dev/null && cp gpurun_out/roofline_peak.jsonl $O/roofline_peak.jsonl
 bash tools/simscale2.sh > $O/simulated_tile_shards.txt 2>&1
