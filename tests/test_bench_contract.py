@@ -1,5 +1,6 @@
 """The bench line's contract (driver side): required keys, types and the two extra objects, checked on the committed artefact of the
-latest run (profiles/r01_u_bench_atrium.json, produced by `python bench.py` on an MI355X) and on bench.py's own argument defaults."""
+latest run (the newest profiles/r*_bench_atrium.json, produced by `python bench.py` on an MI355X through tools/profile_round.sh) and on
+bench.py's own argument defaults."""
 import json
 import os
 import re
@@ -8,7 +9,9 @@ from util import REPO
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(REPO, "profiles", "r01_u_bench_atrium.json")).read().strip().splitlines()[-1]
+    import glob
+    newest = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9][a-z]_bench_atrium.json")))[-1]
+    line = open(newest).read().strip().splitlines()[-1]
     j = json.loads(line)
     for k, t in {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float,
                  "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict, "cpu_baseline": dict}.items():
@@ -16,7 +19,13 @@ def test_committed_bench_line_has_the_contract_fields():
     assert j["vs_baseline"] is None and j["dtype"] == "f32" and j["scaling"] == "strong" and j["higher_is_better"] is True
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+    # the bound is what binds (VALU issue): units of the algorithm per second against a ceiling measured in the same run
+    assert r["bound"] == "valu" and r["kernel"] in ("k_trace_any", "k_trace_closest") and "equivalents/s" in r["unit"]
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0 and r["frac_one_frame_at_a_time"] <= 1.0
+    assert r["hbm"]["peak_GBps"] == 8000.0 and 0.0 < r["hbm"]["traffic_frac_of_peak"] < 1.0
+    assert os.path.exists(os.path.join(REPO, r["hbm"]["traffic_source"]))
+    g = r["other"]["k_trace_closest"]["gather"]
+    assert 0.0 < g["frac"] <= 1.0 and os.path.exists(os.path.join(REPO, g["ceiling_source"]))
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
     assert j["parity"] == {"max_abs_rgb_vs_oracle": 0.0, "pixels_differing": 0, "packed_mismatch": 0, "stats_equal": True}
