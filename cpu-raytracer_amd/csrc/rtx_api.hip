@@ -53,7 +53,7 @@ struct rtx_ctx {
     std::vector<void *> tex_allocs;
     int material_count = 0, sky_size = 0;
     // host copies for validate_references(): every id a kernel will follow is checked on the host before anything is launched
-    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true; int lane_from_level = -1; bool no_wide = false;
+    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true; int lane_from_level = -1; bool no_wide = false; int split_items = 0, item_blocks = 0; DevBuf d_pk_items, d_pk_item_count;
 
     // per-frame state (rtx_set_frame): ONE device block, filled by one asynchronous copy on the context's stream from a ring of pinned
     // staging buffers — the host never waits for the GPU between frames (cfg5: Scene::update + TLAS rebuild every frame)
@@ -157,6 +157,8 @@ static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, st
     // need more packet-stack entries than the cap, the node falls back to the order that minimises the need (smallest need first).
     int order_mode = 1; if (const char * e = getenv("RTX_PK4_ORDER")) order_mode = atoi(e);      // 0: always smallest need first (A/B runs)
     auto area = [&](int i) { const double dx = (double)nodes[i].aabb_max[0] - nodes[i].aabb_min[0], dy = (double)nodes[i].aabb_max[1] - nodes[i].aabb_min[1], dz = (double)nodes[i].aabb_max[2] - nodes[i].aabb_min[2]; const double v = dx * dy + dy * dz + dz * dx; return v == v ? (v < 1e300 ? v : 1e300) : 0.0; };      // a total order even for infinite boxes
+    std::vector<long long> subtree((size_t)n, 0);                   // triangle references below each node
+    for (int i = 0; i < n; i++) if ((nodes[i].count & 0x3fffffff) > 0) subtree[i] = nodes[i].count & 0x3fffffff;
     for (size_t k = order.size(); k-- > 0; ) {                      // children before parents
         const int j = order[k], l = nodes[j].left_or_first;
         int slot[4], ns = 0;
@@ -169,11 +171,14 @@ static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, st
         if (order_mode != 0) { std::sort(slot, slot + ns, [&](int a, int b) { return area(a) > area(b); }); nd = need_of(slot); }
         if (nd > RTX_PK4_MAX_NEED - 4) { std::sort(slot, slot + ns, [&](int a, int b) { return need[a] < need[b]; }); nd = need_of(slot); }
         need[j] = nd;
+        subtree[j] = subtree[l] + subtree[l + 1];
         float4 * rec = &out[(size_t)4 * l];                         // 64 B per unit of `left`, 128 B per record (left is even)
         for (int s = 0; s < ns; s++) {
             const rtx_bvh_node & c = nodes[slot[s]];
             float f, cn; const int cnt = c.count & 0x3fffffff;
-            memcpy(&f, &c.left_or_first, 4); memcpy(&cn, &cnt, 4);
+            // inner slots carry min(255, triangles below) in the top byte of `first` (indices are < 2^24): the walk hands only small subtrees to lanes
+            const int first = cnt > 0 ? c.left_or_first : (c.left_or_first | (int)((uint32_t)(subtree[slot[s]] < 255 ? subtree[slot[s]] : 255) << 24));
+            memcpy(&f, &first, 4); memcpy(&cn, &cnt, 4);
             rec[2 * s]     = make_float4(c.aabb_min[0], c.aabb_min[1], c.aabb_max[0], c.aabb_max[1]);
             rec[2 * s + 1] = make_float4(c.aabb_min[2], c.aabb_max[2], f, cn);
         }
@@ -260,6 +265,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     if (c->trace_blocks_count > max_blocks) max_blocks = c->trace_blocks_count;
     if (c->pk_blocks_any > max_blocks) max_blocks = c->pk_blocks_any;       // the packet kernels' per-lane phase spills there too
     if (c->pk_blocks_closest > max_blocks) max_blocks = c->pk_blocks_closest;
+    { int ib = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&ib, k_items, RTX_PK_BLOCK, 0); if (c->n_cu * (ib > 0 ? ib : 4) * 2 > max_blocks) max_blocks = c->n_cu * (ib > 0 ? ib : 4) * 2; }
     c->q.pk_defer_t0 = 8; if (const char * e = getenv("RTX_PK_DEFER")) c->q.pk_defer_t0 = atoi(e);
     c->q.pk_defer_leaf = c->q.pk_defer_t0 / 2; if (const char * e = getenv("RTX_PK_DEFER_LEAF")) c->q.pk_defer_leaf = atoi(e);
     c->q.pk_defer_t0_closest = 64; if (const char * e = getenv("RTX_PK_DEFER_CLOSEST")) c->q.pk_defer_t0_closest = atoi(e);
@@ -270,6 +276,17 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->q.spill_threads = max_blocks * RTX_TRACE_BLOCK;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast
     if (!rc) rc = ensure(c, c->d_pk_fifo, (size_t)c->q.spill_threads * RTX_PK_FIFO * 4);
+    { int ib = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&ib, k_items, RTX_PK_BLOCK, 0); c->item_blocks = c->n_cu * (ib > 0 ? ib : 4);
+      if (const char * e = getenv("RTX_ITEM_GRID")) { const double f = atof(e); if (f > 0.0) c->item_blocks = (int)(c->n_cu * f); } }
+    if (const char * e = getenv("RTX_PK_SPLIT")) c->split_items = atoi(e);       // items per chunk of the split shadow-ray walk (0 = off)
+    c->q.pk_items = nullptr; c->q.pk_item_count = nullptr; c->q.pk_item_cap = 0;
+    c->q.pk_item_smax = 255; if (const char * e = getenv("RTX_PK_ITEM_SMAX")) c->q.pk_item_smax = atoi(e);
+    if (!rc && c->split_items > 0) {
+        const size_t chunks = (size_t)c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE);
+        rc = ensure(c, c->d_pk_items, chunks * (size_t)c->split_items * 48);
+        if (!rc) rc = ensure(c, c->d_pk_item_count, chunks * 4);
+        if (!rc) { hipMemset(c->d_pk_item_count.p, 0, chunks * 4); c->q.pk_items = (uint4 *)c->d_pk_items.p; c->q.pk_item_count = (uint32_t *)c->d_pk_item_count.p; c->q.pk_item_cap = c->split_items; }
+    }
     if (rc) { rtx_destroy(c); return rc; }
     *out_ctx = c;
     return RTX_OK;
@@ -684,9 +701,19 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
                 else                hipLaunchKernelGGL((k_packet<false, false>), dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
             });
         };
+        // split shadow-ray walk (RTX_PK_SPLIT): the items the packet launch emitted, one per lane
+        bool split = q.pk_items != nullptr;                   // needs 4-wide records for every mesh
+        for (size_t b = 0; b < c->h_blas.size(); b++) if (c->h_blas[b].nodes && !c->h_blas[b].pk4_nodes) split = false;
+        if (!split) { q.pk_items = nullptr; q.pk_item_count = nullptr; q.pk_item_cap = 0; }
+        auto launch_items = [&](hipStream_t st) {
+            if (!split) return;
+            const int batches = (q.pk_item_cap + RTX_WAVE - 1) / RTX_WAVE, chunks = c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE);
+            launch_timed(c, "k_trace_items", st, [&] { hipLaunchKernelGGL(k_items, dim3(c->item_blocks), dim3(RTX_PK_BLOCK), 0, st, sc, q, chunks, batches); });
+        };
         auto launch_any = [&](hipStream_t st, int lo, int hi) {
             if (!count_work && !simple && !lane && !pstat && hi >= lane_from) {      // levels lo .. lane_from-1 by packets, the rest per lane
-                if (lo < lane_from) launch_timed(c, "k_trace_any", st, [&] { hipLaunchKernelGGL((k_packet<true, false>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, lane_from - 1); });
+                if (lo < lane_from) { launch_timed(c, "k_trace_any", st, [&] { if (split) hipLaunchKernelGGL((k_packet<true, false, true>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, lane_from - 1);
+                                                                                 else       hipLaunchKernelGGL((k_packet<true, false>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, lane_from - 1); }); launch_items(st); }
                 const int l0 = lo > lane_from ? lo : lane_from;
                 launch_timed(c, "k_trace_any", st, [&] { hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, st, sc, q, l0, hi); });
                 return;
@@ -696,8 +723,10 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
                 else if (simple)    hipLaunchKernelGGL((k_trace<true, false>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, st, sc, q, lo);
                 else if (lane)      hipLaunchKernelGGL((k_trace_fast<true>),    dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, st, sc, q, lo, hi);
                 else if (pstat)     hipLaunchKernelGGL((k_packet<true, true>),  dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, hi);
+                else if (split)     hipLaunchKernelGGL((k_packet<true, false, true>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, hi);
                 else                hipLaunchKernelGGL((k_packet<true, false>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, hi);
             });
+            if (!count_work && !simple && !lane && !pstat) launch_items(st);
         };
         for (int level = 0; level < levels; level++) {
             launch_closest(level);

@@ -138,7 +138,11 @@ struct DevQueues {
     int32_t       pk_defer_t0_closest;   // the same threshold for closest-hit packets (64 = every lane walks its ray privately from the BLAS root)
     int32_t       pk_defer_t0;    // hybrid any-hit walk: nodes wanted by at most this many lanes (+ walk length / 8) go to the lanes' private stacks
     int32_t       pk_defer_leaf;  // the same for leaves (a leaf costs the packet one triangle test per triangle)
-    int32_t       pk_pad0;
+    int32_t       pk_item_cap;    // split walk: items per chunk (one chunk per wave of the shadow-ray packet launch); pk_items == null: off
+    uint4 *       pk_items;       // (ray slot, leaf count << 24 | first, instance, -)
+    uint32_t *    pk_item_count;  // items in each chunk
+    int32_t       pk_item_smax;   // only nodes with at most this many triangles below are handed over (255 = any)
+    int32_t       pk_pad1;
     DevCounters * counters;
     uint32_t *    stats_partial;  // [level][k_shade block][4]: per-block ray tallies, summed by k_resolve(level 0) (no atomics at the end of k_shade)
     int32_t       shade_blocks;

@@ -43,6 +43,9 @@
 #ifndef RTX_PK_WAVES_ANY
 #define RTX_PK_WAVES_ANY 5           // __launch_bounds__ min waves per SIMD (93 VGPRs unconstrained; forcing 8 waves spills 26 dwords per lane)
 #endif
+#ifndef RTX_PK_WAVES_SPLIT
+#define RTX_PK_WAVES_SPLIT 5         // the split shadow-ray kernel (no per-lane phases): 78 VGPRs, no spills
+#endif
 #ifndef RTX_PK_WAVES_CLOSEST
 #define RTX_PK_WAVES_CLOSEST 4
 #endif
@@ -122,6 +125,7 @@ struct PkWalk {                      // everything a packet walk carries; wave-u
     int fifo_n;                                          // per lane: entries on the lane's private work list (closest-hit hybrid)
     int psp;                                             // per lane: entries on the lane's PRIVATE stack (hybrid any-hit walk)
     int pk_steps;                                        // steps of the current packet walk (the deferral threshold grows with it)
+    int item_n, cur_blas; uint32_t item_slot;            // split walk: items this wave has appended to its chunk, the mesh being walked; per lane: the ray's slot
     uint32_t err;
     unsigned long long st_pairs, st_tris, st_pair_lanes, st_tri_lanes;
 #ifdef RTX_PK_PROF
@@ -644,11 +648,13 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
         "v_writelane_b32 %[stmlo], s92, m0\n\t"                                                                                     \
         "v_writelane_b32 %[stmhi], s93, m0\n\t"                                                                                     \
         "PKB_SET" #K "_%=:\n\t"
-RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds, int defer_t0, int defer_leaf, int grow_shift) {
+RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds, int defer_t0, int defer_leaf, int grow_shift,
+                              uint32_t item_cap, unsigned long long item_base, uint32_t slot, int smax) {
     W.cur_first = rfl(W.cur_first); W.cur_cnt = rfl(W.cur_cnt & 0x3fffffff); W.m = rfl64(W.m); W.alive = rfl64(W.alive); W.sp = rfl(W.sp);
     int err = 0, steps = rfl(W.pk_steps);
     const int floor_sp = rfl(W.floor_sp);
-    defer_t0 = rfl(defer_t0); defer_leaf = rfl(defer_leaf); grow_shift = rfl(grow_shift);
+    defer_t0 = rfl(defer_t0); defer_leaf = rfl(defer_leaf); grow_shift = rfl(grow_shift); smax = rfl(smax);
+    int icnt = rfl(W.item_n); const int icap = rfl((int)item_cap), inst = rfl(W.cur_blas); item_base = rfl64(item_base);
     const float eps = RAY_EPSILON;
     const unsigned long long nodes = rfl64((unsigned long long)nodes4), tris = rfl64((unsigned long long)W.tris);
     float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;          // triangle-test temporaries
@@ -665,12 +671,16 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
         "s_cselect_b32 s91, %[tld], %[t0d]\n\t"
         "s_add_i32 s90, s90, s91\n\t"
         "s_cmp_le_u32 s89, s90\n\t"
+        "s_cbranch_scc0 PKB_NODEFER_%=\n\t"
+        "s_lshr_b32 s91, %[first], 24\n\t"                 // inner nodes carry min(255, triangles below) in the top byte of `first`:
+        "s_cmp_le_u32 s91, %[smax]\n\t"                    // only subtrees up to smax triangles are handed over (255 = any)
         "s_cbranch_scc1 PKB_DEFER_%=\n\t"
         "PKB_NODEFER_%=:\n\t"
         "s_cmp_lg_u32 %[cnt], 0\n\t"
         "s_cbranch_scc1 PKB_LEAF_%=\n\t"
         // ---------------- inner node: four slots ----------------
-        "s_lshl_b32 s88, %[first], 6\n\t"
+        "s_and_b32 s88, %[first], 0xffffff\n\t"
+        "s_lshl_b32 s88, s88, 6\n\t"
         "s_load_dwordx16 s[48:63], s[94:95], s88\n\t"
         "s_add_u32 s88, s88, 64\n\t"
         "s_load_dwordx16 s[64:79], s[94:95], s88\n\t"
@@ -722,12 +732,50 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
         "s_branch PKB_SET0_%=\n\t"
         // ---------------- defer: push the node on the private stacks of the lanes in m ----------------
         "PKB_DEFER_%=:\n\t"
+        "s_cmp_eq_u32 %[icap], 0\n\t"
+        "s_cbranch_scc1 PKB_DEFER_LDS_%=\n\t"
+        // split walk: items (model-space ray, ray slot, node, mesh; 48 bytes) appended to this wave's own chunk — no atomics; k_items walks them one per lane
+        "s_add_u32 s88, %[icnt], 64\n\t"
+        "s_cmp_gt_u32 s88, %[icap]\n\t"
+        "s_cbranch_scc1 PKB_NODEFER_%=\n\t"                 // chunk full: the packet keeps the node
+        "s_and_b32 s88, %[first], 0xffffff\n\t"
+        "s_lshl_b32 s89, %[cnt], 24\n\t"
+        "s_or_b32 s89, s89, s88\n\t"
+        "s_mov_b64 s[92:93], %[m]\n\t"
+        "s_mov_b64 s[84:85], exec\n\t"
+        "s_mov_b64 exec, %[m]\n\t"
+        "v_mbcnt_lo_u32_b32 v24, s92, 0\n\t"
+        "v_mbcnt_hi_u32_b32 v24, s93, v24\n\t"              // rank of the lane among the lanes of m
+        "v_add_u32 v24, %[icnt], v24\n\t"
+        "v_lshl_add_u32 v24, v24, 1, v24\n\t"               // x 3
+        "v_lshlrev_b32 v24, 4, v24\n\t"                     // x 16: 48 bytes per item
+        "v_mov_b32 v28, %[ox]\n\t"
+        "v_mov_b32 v29, %[oy]\n\t"
+        "v_mov_b32 v30, %[oz]\n\t"
+        "v_mov_b32 v31, %[tcur]\n\t"
+        "global_store_dwordx4 v24, v[28:31], %[ibase]\n\t"
+        "s_nop 1\n\t"                                        // store data of more than 64 bits, then a VALU write of those registers: 1 wait state
+        "v_mov_b32 v28, %[dx]\n\t"
+        "v_mov_b32 v29, %[dy]\n\t"
+        "v_mov_b32 v30, %[dz]\n\t"
+        "v_mov_b32 v31, %[slot]\n\t"
+        "global_store_dwordx4 v24, v[28:31], %[ibase] offset:16\n\t"
+        "s_nop 1\n\t"
+        "v_mov_b32 v28, s89\n\t"
+        "v_mov_b32 v29, %[inst]\n\t"
+        "global_store_dwordx2 v24, v[28:29], %[ibase] offset:32\n\t"
+        "s_bcnt1_i32_b64 s88, s[92:93]\n\t"
+        "s_add_u32 %[icnt], %[icnt], s88\n\t"
+        "s_mov_b64 exec, s[84:85]\n\t"
+        "s_branch PKB_POP_%=\n\t"
+        "PKB_DEFER_LDS_%=:\n\t"
         "v_cmp_le_u32 vcc, 8, %[psp]\n\t"                   // every lane of m needs room on its private stack
         "s_and_b64 s[84:85], vcc, %[m]\n\t"
         "s_cmp_lg_u64 s[84:85], 0\n\t"
         "s_cbranch_scc1 PKB_NODEFER_%=\n\t"
+        "s_and_b32 s88, %[first], 0xffffff\n\t"
         "s_lshl_b32 s89, %[cnt], 24\n\t"
-        "s_or_b32 s89, s89, %[first]\n\t"
+        "s_or_b32 s89, s89, s88\n\t"
         "s_mov_b64 s[84:85], exec\n\t"
         "s_mov_b64 exec, %[m]\n\t"
         "v_lshl_add_u32 %[t0], %[psp], 8, %[llds]\n\t"
@@ -761,24 +809,25 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
         "s_branch PKB_DISPATCH_%=\n\t"
         "PKB_END_%=:\n\t"
         : [first] "+&s"(W.cur_first), [cnt] "+&s"(W.cur_cnt), [m] "+&s"(W.m), [alive] "+&s"(W.alive), [sp] "+&s"(W.sp),
-          [err] "+&s"(err), [steps] "+&s"(steps),
+          [err] "+&s"(err), [steps] "+&s"(steps), [icnt] "+&s"(icnt),
           [sta] "+&v"(W.st_a), [stb] "+&v"(W.st_b), [stmlo] "+&v"(W.st_mlo), [stmhi] "+&v"(W.st_mhi), [psp] "+&v"(W.psp),
           [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7),
           [t8] "=&v"(t8), [t9] "=&v"(t9)
         : [nodes] "s"(nodes), [tris] "s"(tris), [floor] "s"(floor_sp),
           [oxy] "v"(W.ray.o_xy), [ozz] "v"(W.ray.o_zz), [ixy] "v"(W.ray.i_xy), [izz] "v"(W.ray.i_zz), [tcur] "v"(W.ray.tcur),
           [ox] "v"(W.ray.o_xy.x), [oy] "v"(W.ray.o_xy.y), [oz] "v"(W.ray.o_zz.x), [dx] "v"(W.ray.d.x), [dy] "v"(W.ray.d.y), [dz] "v"(W.ray.d.z),
-          [eps] "s"(eps), [t0d] "s"(defer_t0), [tld] "s"(defer_leaf), [gsh] "s"(grow_shift), [llds] "v"(lane_lds)
+          [eps] "s"(eps), [t0d] "s"(defer_t0), [tld] "s"(defer_leaf), [gsh] "s"(grow_shift), [llds] "v"(lane_lds),
+          [icap] "s"(icap), [ibase] "s"(item_base), [inst] "s"(inst), [slot] "v"(slot), [smax] "s"(smax)
         : "vcc", "scc", "m0", "memory",
           "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
           "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
           "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
           "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
-    W.pk_steps = steps;
+    W.pk_steps = steps; W.item_n = icnt;
     if (err) W.err = 1;
 }
 
-struct PkHybrid { int * stk; float * stk_key; uint32_t lane_lds; int * spill; float * spill_key; int spill_stride; int * fifo; int fifo_stride; int t0, t_leaf, grow; };
+struct PkHybrid { int * stk; float * stk_key; uint32_t lane_lds; int * spill; float * spill_key; int spill_stride; int * fifo; int fifo_stride; int t0, t_leaf, grow; uint32_t item_cap; unsigned long long item_base; int item_smax; };
 
 // ---- hybrid any-hit walk, per-lane phase -----------------------------------------------------------------------------------------
 // Walks the subtrees the packet walk handed to the lanes' private stacks (entries are nodes that already passed the lane's slab test,
@@ -884,8 +933,8 @@ RTX_D void pk_lane_phase_any4(PkWalk & W, const int lane, const uint32_t lane_ld
             const float4 a0 = gld(nodes4, base), a1 = gld(nodes4, base + 1), b0 = gld(nodes4, base + 2), b1 = gld(nodes4, base + 3);
             const float4 c0 = gld(nodes4, base + 4), c1 = gld(nodes4, base + 5), d0 = gld(nodes4, base + 6), d1 = gld(nodes4, base + 7);
             const bool p0 = pk_slab<true>(a0, a1, W.ray), p1 = pk_slab<true>(b0, b1, W.ray), p2 = pk_slab<true>(c0, c1, W.ray), p3 = pk_slab<true>(d0, d1, W.ray);
-            const int e1 = (int)(((uint32_t)as_i(b1.w) << 24) | (uint32_t)as_i(b1.z)), e2 = (int)(((uint32_t)as_i(c1.w) << 24) | (uint32_t)as_i(c1.z));
-            const int e3 = (int)(((uint32_t)as_i(d1.w) << 24) | (uint32_t)as_i(d1.z));
+            const int e1 = (int)(((uint32_t)as_i(b1.w) << 24) | ((uint32_t)as_i(b1.z) & 0x00ffffffu)), e2 = (int)(((uint32_t)as_i(c1.w) << 24) | ((uint32_t)as_i(c1.z) & 0x00ffffffu));
+            const int e3 = (int)(((uint32_t)as_i(d1.w) << 24) | ((uint32_t)as_i(d1.z) & 0x00ffffffu));
             // slot k is pushed when it passes and a lower slot passes too (that one is walked first)
             const bool q3 = p3 & (p0 | p1 | p2), q2 = p2 & (p0 | p1), q1 = p1 & p0;
             if (psp + 3 <= RTX_PK_PRIV) {
@@ -894,7 +943,7 @@ RTX_D void pk_lane_phase_any4(PkWalk & W, const int lane, const uint32_t lane_ld
                 if (q1) { stk[psp * RTX_WAVE] = e1; psp++; }
             } else { if (q3) push(e3); if (q2) push(e2); if (q1) push(e1); }
             have_cur = p0 | p1 | p2 | p3;
-            cur_first = p0 ? as_i(a1.z) : (p1 ? as_i(b1.z) : (p2 ? as_i(c1.z) : as_i(d1.z)));
+            cur_first = (p0 ? as_i(a1.z) : (p1 ? as_i(b1.z) : (p2 ? as_i(c1.z) : as_i(d1.z)))) & 0x00ffffff;      // without the size byte
             cur_cnt   = p0 ? as_i(a1.w) : (p1 ? as_i(b1.w) : (p2 ? as_i(c1.w) : as_i(d1.w)));
         }
         if (live && have_cur && cur_cnt > 0) {
@@ -1025,7 +1074,7 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
 // Walks until the packet is finished (returns true) or, FAST only, until an instance is entered in which some lane's inverse
 // direction is not finite (returns false: the caller continues with the reference-form variant; the state is consistent).
 // `world(o, d)` reloads a lane's world-space ray (kept in memory, not in registers).
-template <bool ANY, bool PSTAT, bool FAST, bool ASM, typename WorldFn>
+template <bool ANY, bool PSTAT, bool FAST, bool ASM, bool SPLIT, typename WorldFn>
 RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool ordered, const PkHybrid & H, WorldFn && world) {
     for (;;) {
         if (W.m != 0ull) {
@@ -1149,7 +1198,8 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
             v3 o, d; world(o, d);
             const v3 co = xform_pos(I.world_inv, o), cd = xform_dir(I.world_inv, d), cinv = vrcp(cd);
             pk_set_ray(W.ray, co, cd, cinv);
-            const DevBlas & B = sc.blas[rfl(I.blas_id)];
+            W.cur_blas = rfl(I.blas_id);
+            const DevBlas & B = sc.blas[W.cur_blas];
             W.nodes = pk_cptr(B.pk_nodes); W.tris = pk_cptr(B.tri_hot); W.cur_inst = inst;
             W.lane_nodes = RTX_GPTR(B.nodes); W.lane_tris = RTX_GPTR(B.tri_hot);
             W.floor_sp = W.sp; W.depth = 0;
@@ -1162,8 +1212,12 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
                 // the whole BLAS walk, hand-scheduled (returns with m == 0), then the per-lane phase over what it deferred
                 PK_T0();
                 W.psp = 0;
-                if (B.pk4_nodes) {                                   // nested boxes: the 4-wide records
-                    pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.t_leaf, H.grow);
+                if ((SPLIT || B.pk4_nodes) && (W.cur_cnt & 0x3fffffff) == 0) W.cur_first |= (int)0xff000000u;      // an inner root counts as a big subtree (the size byte of `first`)
+                if (SPLIT) {                                         // split walk (every mesh has 4-wide records): deferred nodes become items, no per-lane phase here
+                    pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.t_leaf, H.grow, H.item_cap, H.item_base, W.item_slot, H.item_smax);
+                    PK_T1(1);
+                } else if (B.pk4_nodes) {                            // nested boxes: the 4-wide records
+                    pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.t_leaf, H.grow, 0u, 0ull, 0u, 255);
                     PK_T1(1);
                     if (W.alive != 0ull && __ballot(W.psp > 0) != 0ull) { PK_T0(); pk_lane_phase_any4(W, lane, H.lane_lds, H.spill, H.spill_stride, RTX_GPTR(B.pk4_nodes), RTX_GPTR(B.tri_hot)); PK_T1(2); }
                 } else {
@@ -1187,16 +1241,16 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
     }
 }
 
-template <bool ANY, bool PSTAT>
-__global__ __launch_bounds__(RTX_PK_BLOCK, ANY ? RTX_PK_WAVES_ANY : RTX_PK_WAVES_CLOSEST)
+template <bool ANY, bool PSTAT, bool SPLIT = false>
+__global__ __launch_bounds__(RTX_PK_BLOCK, ANY ? (SPLIT ? RTX_PK_WAVES_SPLIT : RTX_PK_WAVES_ANY) : RTX_PK_WAVES_CLOSEST)
 void k_packet(const DevScene sc, const DevQueues q, const int level, const int level_hi) {
     // hybrid any-hit walk: the lanes' private stacks, striped through LDS ([entry][lane]: conflict-free)
     // closest-hit: RTX_LDS_STACK entries + their pop-time keys (the per-lane kernels' stack layout, rtx_trace.h)
-    __shared__ int s_priv[RTX_PK_BLOCK / RTX_WAVE][ANY ? RTX_PK_PRIV : 2 * RTX_LDS_STACK][RTX_WAVE];
+    __shared__ int s_priv[RTX_PK_BLOCK / RTX_WAVE][SPLIT ? 1 : (ANY ? RTX_PK_PRIV : 2 * RTX_LDS_STACK)][RTX_WAVE];
     const int lane = threadIdx.x & 63;
     PkHybrid H;
     H.stk = &s_priv[threadIdx.x >> 6][0][lane];
-    H.stk_key = (float *)&s_priv[threadIdx.x >> 6][ANY ? 0 : RTX_LDS_STACK][lane];
+    H.stk_key = (float *)&s_priv[threadIdx.x >> 6][(ANY || SPLIT) ? 0 : RTX_LDS_STACK][lane];
     H.lane_lds = (uint32_t)(uintptr_t)H.stk;
     H.spill_stride = q.spill_threads;
     {   // spill regions of rtx_trace.h: [0, S) closest entries, [S, 2S) closest keys, [2S, 3S) shadow-ray entries
@@ -1206,9 +1260,11 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
         H.fifo = q.pk_fifo + gt; H.fifo_stride = q.spill_threads;
     }
     H.t0 = ANY ? q.pk_defer_t0 : q.pk_defer_t0_closest; H.t_leaf = q.pk_defer_leaf; H.grow = q.pk_defer_grow;
+    H.item_cap = 0; H.item_base = 0ull; H.item_smax = q.pk_item_smax;
     const uint32_t gwave  = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
     const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE);
 
+    if (ANY && SPLIT && q.pk_items) { H.item_cap = (uint32_t)q.pk_item_cap; H.item_base = (unsigned long long)(q.pk_items + 3 * (size_t)gwave * (size_t)q.pk_item_cap); }
     DevCounters * const ctr = q.counters;
     const int nL = sc.light_count;
     // packets: closest-hit = consecutive 64-slot groups of the level's queue; any-hit = per (level, light) segment, each padded
@@ -1226,7 +1282,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
     const unsigned long long pk_k0_ = __builtin_amdgcn_s_memtime();
 #endif
     W.tlas = pk_cptr(sc.pk_tlas_nodes);
-    W.err = 0; W.st_pairs = W.st_tris = W.st_pair_lanes = W.st_tri_lanes = 0ull;
+    W.err = 0; W.st_pairs = W.st_tris = W.st_pair_lanes = W.st_tri_lanes = 0ull; W.item_n = 0; W.item_slot = 0; W.cur_blas = 0;
     W.st_a = W.st_b = W.st_mlo = W.st_mhi = W.st_idx = W.st_df = 0;
     unsigned long long st_packets = 0ull;
 
@@ -1312,7 +1368,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
                 if ((t > RAY_EPSILON) & (t < W.ray.tcur)) { if (ANY) { W.occluded = true; break; } else { W.ray.tcur = t; W.best_prim = PRIM_PLANE | i; } }
             }
         }
-        W.psp = 0; W.pk_steps = 0; W.fifo_n = 0;
+        W.psp = 0; W.pk_steps = 0; W.fifo_n = 0; W.item_slot = out_slot;
         W.alive = __ballot(W.valid && !W.occluded);     // any-hit: lanes leave when occluded; closest-hit: constant
         const unsigned long long alive0 = W.alive;
         W.pub = W.alive;
@@ -1334,8 +1390,8 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
             const unsigned long long pk_w0_ = __builtin_amdgcn_s_memtime();
 #endif
             bool done = false;
-            if (nanfree_world) done = pk_walk<ANY, PSTAT, true, !PSTAT>(sc, W, lane, ordered, H, world);
-            if (!done) pk_walk<ANY, PSTAT, false, false>(sc, W, lane, ordered, H, world);
+            if (nanfree_world) done = pk_walk<ANY, PSTAT, true, !PSTAT, SPLIT>(sc, W, lane, ordered, H, world);
+            if (!done) pk_walk<ANY, PSTAT, false, false, SPLIT>(sc, W, lane, ordered, H, world);
 #ifdef RTX_PK_PROF
             {   // slot 4: the longest single packet walk (max), slot 9: walks longer than 2^18 ticks
                 const unsigned long long dt = __builtin_amdgcn_s_memtime() - pk_w0_;
@@ -1357,10 +1413,90 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
     W.prof[8] = (1ull << 62) - pk_k0_;                           // first start (max of the complement)
     if (lane == 0) for (int i = 0; i < 10; i++) { if (i == 4 || i == 5 || i == 7 || i == 8 || i == 9) atomicMax(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); else atomicAdd(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); }
 #endif
+    if (ANY && SPLIT && q.pk_items && lane == 0) q.pk_item_count[gwave] = (uint32_t)W.item_n;
     if (W.err) { if (lane == 0) atomicOr(&ctr->error_flags, ERR_STACK_OVERFLOW); }
     if (PSTAT && lane == 0) {
         atomicAdd(&ctr->work[15 + PKS_PACKETS], st_packets); atomicAdd(&ctr->work[15 + PKS_PAIR_STEPS], W.st_pairs);
         atomicAdd(&ctr->work[15 + PKS_TRI_STEPS], W.st_tris); atomicAdd(&ctr->work[15 + PKS_PAIR_LANES], W.st_pair_lanes);
         atomicAdd(&ctr->work[15 + PKS_TRI_LANES], W.st_tri_lanes);
+    }
+}
+
+// ---- split walk, second half: the items the shadow-ray packet kernel emitted, one item per lane ----------------------------------------
+// An item = (model-space origin, max distance) (model-space direction, ray slot) (node that passed the ray's test, mesh): 48 bytes, written by
+// the packet walk where few lanes wanted a node.  They are tiny (1.15 per-lane steps on average in the cfg3 frame) and there are millions of
+// them.  Unit of work = 64 consecutive items of one chunk (chunk c = what wave c of the packet launch emitted); units are numbered batch-major
+// (unit u = batch u / chunks of chunk u % chunks) and dealt round-robin to the waves of a persistent grid, so every wave gets the same mix
+// of full, partial and empty units without any queue.  A lane walks its item's subtree over the 4-wide records with a private stack (LDS,
+// then scratch); a hit sets the ray's occlusion flag (the packet kernel wrote 0 or 1 before); a ray already flagged skips its items.
+#define RTX_ITEM_LDS 8
+#ifndef RTX_ITEM_WAVES
+#define RTX_ITEM_WAVES 6          // 80 VGPRs: no spills (8 waves = 64 VGPRs spills 14 dwords into the loop)
+#endif
+__global__ __launch_bounds__(RTX_PK_BLOCK, RTX_ITEM_WAVES)
+void k_items(const DevScene sc, const DevQueues q, const int n_chunks, const int n_batches) {
+    __shared__ int s_stk[RTX_ITEM_LDS][RTX_PK_BLOCK];
+    const int lane = threadIdx.x & 63;
+    const uint32_t gwave = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
+    const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE), units = (uint32_t)n_chunks * (uint32_t)n_batches;
+    int ovf[RTX_PK4_MAX_NEED + 4];                                                   // stack entries beyond the LDS ones (scratch; rare)
+    for (uint32_t u = gwave; u < units; u += nwaves) {
+        const uint32_t chunk = u % (uint32_t)n_chunks, first = (u / (uint32_t)n_chunks) * 64u;
+        const uint32_t n = (uint32_t)rfl((int)q.pk_item_count[chunk]);
+        if (first >= n) continue;
+        const uint32_t i = first + (uint32_t)lane;
+        bool busy = i < n;
+        const uint4 * const it = q.pk_items + 3 * ((size_t)chunk * (size_t)q.pk_item_cap + (busy ? i : first));
+        const uint4 q0 = it[0], q1 = it[1]; const uint2 q2 = *(const uint2 *)(it + 2);
+        const uint32_t slot = q1.w;
+        const DevBlas & B = sc.blas[q2.y];
+        rtx_gptr nodes4 = RTX_GPTR(B.pk4_nodes), tris = RTX_GPTR(B.tri_hot);
+        if (q.socc[slot] != 0u) busy = false;
+        const v3 co = V3(as_f((int)q0.x), as_f((int)q0.y), as_f((int)q0.z)), cd = V3(as_f((int)q1.x), as_f((int)q1.y), as_f((int)q1.z));
+        PkRay ray; pk_set_ray(ray, co, cd, vrcp(cd)); ray.tcur = as_f((int)q0.w);     // vrcp as at the instance entry of the packet walk: the same bits
+        int psp = 0, cur_first = (int)(q2.x & 0x00ffffffu), cur_cnt = (int)(q2.x >> 24);
+        bool have_cur = true;
+        auto push = [&](int e) { if (psp < RTX_ITEM_LDS) s_stk[psp][threadIdx.x] = e; else if (psp < RTX_ITEM_LDS + RTX_PK4_MAX_NEED + 4) ovf[psp - RTX_ITEM_LDS] = e; psp++; };
+        while (__ballot(busy) != 0ull) {
+            if (busy && have_cur && cur_cnt == 0) {
+                const int base = 4 * cur_first;
+                const float4 a0 = gld(nodes4, base), a1 = gld(nodes4, base + 1), b0 = gld(nodes4, base + 2), b1 = gld(nodes4, base + 3);
+                const float4 c0 = gld(nodes4, base + 4), c1 = gld(nodes4, base + 5), d0 = gld(nodes4, base + 6), d1 = gld(nodes4, base + 7);
+                const bool p0 = pk_slab<true>(a0, a1, ray), p1 = pk_slab<true>(b0, b1, ray), p2 = pk_slab<true>(c0, c1, ray), p3 = pk_slab<true>(d0, d1, ray);
+                if (p3 & (p0 | p1 | p2)) push((int)(((uint32_t)as_i(d1.w) << 24) | ((uint32_t)as_i(d1.z) & 0x00ffffffu)));
+                if (p2 & (p0 | p1))      push((int)(((uint32_t)as_i(c1.w) << 24) | ((uint32_t)as_i(c1.z) & 0x00ffffffu)));
+                if (p1 & p0)             push((int)(((uint32_t)as_i(b1.w) << 24) | ((uint32_t)as_i(b1.z) & 0x00ffffffu)));
+                have_cur = p0 | p1 | p2 | p3;
+                cur_first = (p0 ? as_i(a1.z) : (p1 ? as_i(b1.z) : (p2 ? as_i(c1.z) : as_i(d1.z)))) & 0x00ffffff;
+                cur_cnt   = p0 ? as_i(a1.w) : (p1 ? as_i(b1.w) : (p2 ? as_i(c1.w) : as_i(d1.w)));
+            }
+            if (busy && have_cur && cur_cnt > 0) {
+                have_cur = false;
+                for (int t = cur_first; t < cur_first + cur_cnt; t++) {
+                    const float4 p0 = gld(tris, RTX_TRI_STRIDE * t), e1 = gld(tris, RTX_TRI_STRIDE * t + 1), e2 = gld(tris, RTX_TRI_STRIDE * t + 2);
+                    const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
+                    const v3 h = vcross(cd, edge_2);
+                    const float a = vdot(edge_1, h);
+                    const float f = 1.0f / a;
+                    const v3 sv = vsub(co, V3(p0.x, p0.y, p0.z));
+                    const float uu = f * vdot(sv, h);
+                    if (!((uu > 0.0f) & (uu < 1.0f))) continue;
+                    const v3 qq = vcross(sv, edge_1);
+                    const float v = f * vdot(cd, qq);
+                    if (!((v > 0.0f) & ((uu + v) < 1.0f))) continue;
+                    const float tt = f * vdot(edge_2, qq);
+                    if (!((tt > RAY_EPSILON) & (tt < ray.tcur))) continue;
+                    q.socc[slot] = 1u; busy = false; break;                      // occluded
+                }
+            }
+            if (busy && !have_cur) {
+                if (psp == 0) busy = false;
+                else {
+                    psp--;
+                    const int e = psp < RTX_ITEM_LDS ? s_stk[psp][threadIdx.x] : ovf[psp - RTX_ITEM_LDS];
+                    cur_first = e & 0x00ffffff; cur_cnt = (int)((uint32_t)e >> 24); have_cur = true;
+                }
+            }
+        }
     }
 }
