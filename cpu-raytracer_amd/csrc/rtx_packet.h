@@ -1424,79 +1424,111 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
 
 // ---- split walk, second half: the items the shadow-ray packet kernel emitted, one item per lane ----------------------------------------
 // An item = (model-space origin, max distance) (model-space direction, ray slot) (node that passed the ray's test, mesh): 48 bytes, written by
-// the packet walk where few lanes wanted a node.  They are tiny (1.15 per-lane steps on average in the cfg3 frame) and there are millions of
-// them.  Unit of work = 64 consecutive items of one chunk (chunk c = what wave c of the packet launch emitted); units are numbered batch-major
-// (unit u = batch u / chunks of chunk u % chunks) and dealt round-robin to the waves of a persistent grid, so every wave gets the same mix
-// of full, partial and empty units without any queue.  A lane walks its item's subtree over the 4-wide records with a private stack (LDS,
-// then scratch); a hit sets the ray's occlusion flag (the packet kernel wrote 0 or 1 before); a ray already flagged skips its items.
+// the packet walk where few lanes wanted a node.  Most are tiny (2.5 loop iterations on average in the cfg3 frame, a few take a hundred) and
+// there are millions of them.  Unit of work = 64 consecutive items of one chunk (chunk c = what wave c of the packet launch emitted); units are
+// numbered batch-major (unit u = batch u / chunks of chunk u % chunks) and dealt round-robin to the waves of a persistent grid, so every
+// wave gets the same mix of full, partial and empty units without any queue.  Inside a wave, a lane that finishes its item takes the next
+// one of the wave's units at once (ballot + prefix rank): a long item keeps one lane busy, not 64.  A lane walks its item's subtree over the
+// 4-wide records with a private stack (LDS, then scratch); a hit sets the ray's occlusion flag (the packet kernel wrote 0 or 1 before); a
+// ray already flagged skips its items.
 #define RTX_ITEM_LDS 8
 #ifndef RTX_ITEM_WAVES
-#define RTX_ITEM_WAVES 6          // 80 VGPRs: no spills (8 waves = 64 VGPRs spills 14 dwords into the loop)
+#define RTX_ITEM_WAVES 6
 #endif
 __global__ __launch_bounds__(RTX_PK_BLOCK, RTX_ITEM_WAVES)
 void k_items(const DevScene sc, const DevQueues q, const int n_chunks, const int n_batches) {
     __shared__ int s_stk[RTX_ITEM_LDS][RTX_PK_BLOCK];
-    const int lane = threadIdx.x & 63;
     const uint32_t gwave = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
     const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE), units = (uint32_t)n_chunks * (uint32_t)n_batches;
     int ovf[RTX_PK4_MAX_NEED + 4];                                                   // stack entries beyond the LDS ones (scratch; rare)
-    for (uint32_t u = gwave; u < units; u += nwaves) {
-        const uint32_t chunk = u % (uint32_t)n_chunks, first = (u / (uint32_t)n_chunks) * 64u;
-        const uint32_t n = (uint32_t)rfl((int)q.pk_item_count[chunk]);
-        if (first >= n) continue;
-        const uint32_t i = first + (uint32_t)lane;
-        bool busy = i < n;
-        const uint4 * const it = q.pk_items + 3 * ((size_t)chunk * (size_t)q.pk_item_cap + (busy ? i : first));
-        const uint4 q0 = it[0], q1 = it[1]; const uint2 q2 = *(const uint2 *)(it + 2);
-        const uint32_t slot = q1.w;
-        const DevBlas & B = sc.blas[q2.y];
-        rtx_gptr nodes4 = RTX_GPTR(B.pk4_nodes), tris = RTX_GPTR(B.tri_hot);
-        if (q.socc[slot] != 0u) busy = false;
-        const v3 co = V3(as_f((int)q0.x), as_f((int)q0.y), as_f((int)q0.z)), cd = V3(as_f((int)q1.x), as_f((int)q1.y), as_f((int)q1.z));
-        PkRay ray; pk_set_ray(ray, co, cd, vrcp(cd)); ray.tcur = as_f((int)q0.w);     // vrcp as at the instance entry of the packet walk: the same bits
-        int psp = 0, cur_first = (int)(q2.x & 0x00ffffffu), cur_cnt = (int)(q2.x >> 24);
-        bool have_cur = true;
-        auto push = [&](int e) { if (psp < RTX_ITEM_LDS) s_stk[psp][threadIdx.x] = e; else if (psp < RTX_ITEM_LDS + RTX_PK4_MAX_NEED + 4) ovf[psp - RTX_ITEM_LDS] = e; psp++; };
-        while (__ballot(busy) != 0ull) {
-            if (busy && have_cur && cur_cnt == 0) {
-                const int base = 4 * cur_first;
-                const float4 a0 = gld(nodes4, base), a1 = gld(nodes4, base + 1), b0 = gld(nodes4, base + 2), b1 = gld(nodes4, base + 3);
-                const float4 c0 = gld(nodes4, base + 4), c1 = gld(nodes4, base + 5), d0 = gld(nodes4, base + 6), d1 = gld(nodes4, base + 7);
-                const bool p0 = pk_slab<true>(a0, a1, ray), p1 = pk_slab<true>(b0, b1, ray), p2 = pk_slab<true>(c0, c1, ray), p3 = pk_slab<true>(d0, d1, ray);
-                if (p3 & (p0 | p1 | p2)) push((int)(((uint32_t)as_i(d1.w) << 24) | ((uint32_t)as_i(d1.z) & 0x00ffffffu)));
-                if (p2 & (p0 | p1))      push((int)(((uint32_t)as_i(c1.w) << 24) | ((uint32_t)as_i(c1.z) & 0x00ffffffu)));
-                if (p1 & p0)             push((int)(((uint32_t)as_i(b1.w) << 24) | ((uint32_t)as_i(b1.z) & 0x00ffffffu)));
-                have_cur = p0 | p1 | p2 | p3;
-                cur_first = (p0 ? as_i(a1.z) : (p1 ? as_i(b1.z) : (p2 ? as_i(c1.z) : as_i(d1.z)))) & 0x00ffffff;
-                cur_cnt   = p0 ? as_i(a1.w) : (p1 ? as_i(b1.w) : (p2 ? as_i(c1.w) : as_i(d1.w)));
+#ifdef RTX_ITEM_STATS
+    unsigned long long st_iters = 0, st_busy = 0, st_batches = 0, st_items = 0;
+#endif
+    // the wave's stream of items: units u, u + nwaves, ...; [pos, lim) = what is left of the current unit (wave-uniform)
+    uint32_t u = gwave, pos = 0, lim = 0; const uint4 * items = q.pk_items;
+    auto next_unit = [&]() {
+        for (; u < units; u += nwaves) {
+            const uint32_t chunk = u % (uint32_t)n_chunks, first = (u / (uint32_t)n_chunks) * 64u;
+            const uint32_t n = (uint32_t)rfl((int)q.pk_item_count[chunk]);
+            if (first < n) { pos = first; lim = first + 64u < n ? first + 64u : n; items = q.pk_items + 3 * (size_t)chunk * (size_t)q.pk_item_cap; u += nwaves; return true; }
+        }
+        return false;
+    };
+    bool have_unit = next_unit();
+    // per lane: the item being walked
+    bool busy = false, have_cur = false; uint32_t slot = 0; int psp = 0, cur_first = 0, cur_cnt = 0;
+    v3 co = V3(0.0f, 0.0f, 0.0f), cd = V3(1.0f, 1.0f, 1.0f);
+    PkRay ray; pk_set_ray(ray, co, cd, cd); ray.tcur = 0.0f;
+    rtx_gptr nodes4 = nullptr, tris = nullptr;
+    auto push = [&](int e) { if (psp < RTX_ITEM_LDS) s_stk[psp][threadIdx.x] = e; else if (psp < RTX_ITEM_LDS + RTX_PK4_MAX_NEED + 4) ovf[psp - RTX_ITEM_LDS] = e; psp++; };
+    for (;;) {
+        const unsigned long long idle = __ballot(!busy);
+        if (idle != 0ull && have_unit) {
+            const uint32_t rank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const uint32_t take = (uint32_t)__popcll(idle), avail = lim - pos;
+            if (!busy && rank < avail) {
+                const uint4 * const it = items + 3 * (size_t)(pos + rank);
+                const uint4 q0 = it[0], q1 = it[1]; const uint2 q2 = *(const uint2 *)(it + 2);
+                slot = q1.w;
+                const DevBlas & B = sc.blas[q2.y];
+                nodes4 = RTX_GPTR(B.pk4_nodes); tris = RTX_GPTR(B.tri_hot);
+                co = V3(as_f((int)q0.x), as_f((int)q0.y), as_f((int)q0.z)); cd = V3(as_f((int)q1.x), as_f((int)q1.y), as_f((int)q1.z));
+                pk_set_ray(ray, co, cd, vrcp(cd)); ray.tcur = as_f((int)q0.w);        // vrcp as at the instance entry of the packet walk: the same bits
+                cur_first = (int)(q2.x & 0x00ffffffu); cur_cnt = (int)(q2.x >> 24); have_cur = true; psp = 0;
+                busy = q.socc[slot] == 0u;                                            // already occluded: the item is void
+#ifdef RTX_ITEM_STATS
+                st_items++;
+#endif
             }
-            if (busy && have_cur && cur_cnt > 0) {
-                have_cur = false;
-                for (int t = cur_first; t < cur_first + cur_cnt; t++) {
-                    const float4 p0 = gld(tris, RTX_TRI_STRIDE * t), e1 = gld(tris, RTX_TRI_STRIDE * t + 1), e2 = gld(tris, RTX_TRI_STRIDE * t + 2);
-                    const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
-                    const v3 h = vcross(cd, edge_2);
-                    const float a = vdot(edge_1, h);
-                    const float f = 1.0f / a;
-                    const v3 sv = vsub(co, V3(p0.x, p0.y, p0.z));
-                    const float uu = f * vdot(sv, h);
-                    if (!((uu > 0.0f) & (uu < 1.0f))) continue;
-                    const v3 qq = vcross(sv, edge_1);
-                    const float v = f * vdot(cd, qq);
-                    if (!((v > 0.0f) & ((uu + v) < 1.0f))) continue;
-                    const float tt = f * vdot(edge_2, qq);
-                    if (!((tt > RAY_EPSILON) & (tt < ray.tcur))) continue;
-                    q.socc[slot] = 1u; busy = false; break;                      // occluded
-                }
+            pos += take < avail ? take : avail;
+            if (pos >= lim) have_unit = next_unit();
+        }
+        if (__ballot(busy) == 0ull) { if (!have_unit) break; else continue; }
+#ifdef RTX_ITEM_STATS
+        st_iters++; st_busy += (unsigned long long)__popcll(__ballot(busy));
+#endif
+        if (busy && have_cur && cur_cnt == 0) {
+            const int base = 4 * cur_first;
+            const float4 a0 = gld(nodes4, base), a1 = gld(nodes4, base + 1), b0 = gld(nodes4, base + 2), b1 = gld(nodes4, base + 3);
+            const float4 c0 = gld(nodes4, base + 4), c1 = gld(nodes4, base + 5), d0 = gld(nodes4, base + 6), d1 = gld(nodes4, base + 7);
+            const bool p0 = pk_slab<true>(a0, a1, ray), p1 = pk_slab<true>(b0, b1, ray), p2 = pk_slab<true>(c0, c1, ray), p3 = pk_slab<true>(d0, d1, ray);
+            if (p3 & (p0 | p1 | p2)) push((int)(((uint32_t)as_i(d1.w) << 24) | ((uint32_t)as_i(d1.z) & 0x00ffffffu)));
+            if (p2 & (p0 | p1))      push((int)(((uint32_t)as_i(c1.w) << 24) | ((uint32_t)as_i(c1.z) & 0x00ffffffu)));
+            if (p1 & p0)             push((int)(((uint32_t)as_i(b1.w) << 24) | ((uint32_t)as_i(b1.z) & 0x00ffffffu)));
+            have_cur = p0 | p1 | p2 | p3;
+            cur_first = (p0 ? as_i(a1.z) : (p1 ? as_i(b1.z) : (p2 ? as_i(c1.z) : as_i(d1.z)))) & 0x00ffffff;
+            cur_cnt   = p0 ? as_i(a1.w) : (p1 ? as_i(b1.w) : (p2 ? as_i(c1.w) : as_i(d1.w)));
+        }
+        if (busy && have_cur && cur_cnt > 0) {
+            have_cur = false;
+            for (int t = cur_first; t < cur_first + cur_cnt; t++) {
+                const float4 p0 = gld(tris, RTX_TRI_STRIDE * t), e1 = gld(tris, RTX_TRI_STRIDE * t + 1), e2 = gld(tris, RTX_TRI_STRIDE * t + 2);
+                const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
+                const v3 h = vcross(cd, edge_2);
+                const float a = vdot(edge_1, h);
+                const float f = 1.0f / a;
+                const v3 sv = vsub(co, V3(p0.x, p0.y, p0.z));
+                const float uu = f * vdot(sv, h);
+                if (!((uu > 0.0f) & (uu < 1.0f))) continue;
+                const v3 qq = vcross(sv, edge_1);
+                const float v = f * vdot(cd, qq);
+                if (!((v > 0.0f) & ((uu + v) < 1.0f))) continue;
+                const float tt = f * vdot(edge_2, qq);
+                if (!((tt > RAY_EPSILON) & (tt < ray.tcur))) continue;
+                q.socc[slot] = 1u; busy = false; break;                      // occluded
             }
-            if (busy && !have_cur) {
-                if (psp == 0) busy = false;
-                else {
-                    psp--;
-                    const int e = psp < RTX_ITEM_LDS ? s_stk[psp][threadIdx.x] : ovf[psp - RTX_ITEM_LDS];
-                    cur_first = e & 0x00ffffff; cur_cnt = (int)((uint32_t)e >> 24); have_cur = true;
-                }
+        }
+        if (busy && !have_cur) {
+            if (psp == 0) busy = false;
+            else {
+                psp--;
+                const int e = psp < RTX_ITEM_LDS ? s_stk[psp][threadIdx.x] : ovf[psp - RTX_ITEM_LDS];
+                cur_first = e & 0x00ffffff; cur_cnt = (int)((uint32_t)e >> 24); have_cur = true;
             }
         }
     }
+#ifdef RTX_ITEM_STATS
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&q.counters->work[16], st_iters); atomicAdd(&q.counters->work[17], st_busy); atomicMax(&q.counters->work[19], st_iters); }
+    atomicAdd(&q.counters->work[15], st_items);
+#endif
 }
