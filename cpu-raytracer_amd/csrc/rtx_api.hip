@@ -157,8 +157,6 @@ static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, st
     // need more packet-stack entries than the cap, the node falls back to the order that minimises the need (smallest need first).
     int order_mode = 1; if (const char * e = getenv("RTX_PK4_ORDER")) order_mode = atoi(e);      // 0: always smallest need first (A/B runs)
     auto area = [&](int i) { const double dx = (double)nodes[i].aabb_max[0] - nodes[i].aabb_min[0], dy = (double)nodes[i].aabb_max[1] - nodes[i].aabb_min[1], dz = (double)nodes[i].aabb_max[2] - nodes[i].aabb_min[2]; const double v = dx * dy + dy * dz + dz * dx; return v == v ? (v < 1e300 ? v : 1e300) : 0.0; };      // a total order even for infinite boxes
-    std::vector<long long> subtree((size_t)n, 0);                   // triangle references below each node
-    for (int i = 0; i < n; i++) if ((nodes[i].count & 0x3fffffff) > 0) subtree[i] = nodes[i].count & 0x3fffffff;
     for (size_t k = order.size(); k-- > 0; ) {                      // children before parents
         const int j = order[k], l = nodes[j].left_or_first;
         int slot[4], ns = 0;
@@ -171,14 +169,11 @@ static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, st
         if (order_mode != 0) { std::sort(slot, slot + ns, [&](int a, int b) { return area(a) > area(b); }); nd = need_of(slot); }
         if (nd > RTX_PK4_MAX_NEED - 4) { std::sort(slot, slot + ns, [&](int a, int b) { return need[a] < need[b]; }); nd = need_of(slot); }
         need[j] = nd;
-        subtree[j] = subtree[l] + subtree[l + 1];
         float4 * rec = &out[(size_t)4 * l];                         // 64 B per unit of `left`, 128 B per record (left is even)
         for (int s = 0; s < ns; s++) {
             const rtx_bvh_node & c = nodes[slot[s]];
             float f, cn; const int cnt = c.count & 0x3fffffff;
-            // inner slots carry min(255, triangles below) in the top byte of `first` (indices are < 2^24): the walk hands only small subtrees to lanes
-            const int first = cnt > 0 ? c.left_or_first : (c.left_or_first | (int)((uint32_t)(subtree[slot[s]] < 255 ? subtree[slot[s]] : 255) << 24));
-            memcpy(&f, &first, 4); memcpy(&cn, &cnt, 4);
+            memcpy(&f, &c.left_or_first, 4); memcpy(&cn, &cnt, 4);
             rec[2 * s]     = make_float4(c.aabb_min[0], c.aabb_min[1], c.aabb_max[0], c.aabb_max[1]);
             rec[2 * s + 1] = make_float4(c.aabb_min[2], c.aabb_max[2], f, cn);
         }
@@ -278,9 +273,8 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     if (!rc) rc = ensure(c, c->d_pk_fifo, (size_t)c->q.spill_threads * RTX_PK_FIFO * 4);
     { int ib = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&ib, k_items, RTX_PK_BLOCK, 0); c->item_blocks = c->n_cu * (ib > 0 ? ib : 4);
       if (const char * e = getenv("RTX_ITEM_GRID")) { const double f = atof(e); if (f > 0.0) c->item_blocks = (int)(c->n_cu * f); } }
-    if (const char * e = getenv("RTX_PK_SPLIT")) c->split_items = atoi(e);       // items per chunk of the split shadow-ray walk (0 = off)
+    c->split_items = 2048; if (const char * e = getenv("RTX_PK_SPLIT")) c->split_items = atoi(e);       // items per chunk of the split shadow-ray walk (0 = off)
     c->q.pk_items = nullptr; c->q.pk_item_count = nullptr; c->q.pk_item_cap = 0;
-    c->q.pk_item_smax = 255; if (const char * e = getenv("RTX_PK_ITEM_SMAX")) c->q.pk_item_smax = atoi(e);
     if (!rc && c->split_items > 0) {
         const size_t chunks = (size_t)c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE);
         rc = ensure(c, c->d_pk_items, chunks * (size_t)c->split_items * 48);

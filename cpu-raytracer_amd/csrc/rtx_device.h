@@ -141,8 +141,6 @@ struct DevQueues {
     int32_t       pk_item_cap;    // split walk: items per chunk (one chunk per wave of the shadow-ray packet launch); pk_items == null: off
     uint4 *       pk_items;       // (ray slot, leaf count << 24 | first, instance, -)
     uint32_t *    pk_item_count;  // items in each chunk
-    int32_t       pk_item_smax;   // only nodes with at most this many triangles below are handed over (255 = any)
-    int32_t       pk_pad1;
     DevCounters * counters;
     uint32_t *    stats_partial;  // [level][k_shade block][4]: per-block ray tallies, summed by k_resolve(level 0) (no atomics at the end of k_shade)
     int32_t       shade_blocks;

@@ -649,11 +649,11 @@ RTX_D void pk_blas_any_asm(PkWalk & W, int stack_size, const uint32_t lane_lds, 
         "v_writelane_b32 %[stmhi], s93, m0\n\t"                                                                                     \
         "PKB_SET" #K "_%=:\n\t"
 RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds, int defer_t0, int defer_leaf, int grow_shift,
-                              uint32_t item_cap, unsigned long long item_base, uint32_t slot, int smax) {
+                              uint32_t item_cap, unsigned long long item_base, uint32_t slot) {
     W.cur_first = rfl(W.cur_first); W.cur_cnt = rfl(W.cur_cnt & 0x3fffffff); W.m = rfl64(W.m); W.alive = rfl64(W.alive); W.sp = rfl(W.sp);
     int err = 0, steps = rfl(W.pk_steps);
     const int floor_sp = rfl(W.floor_sp);
-    defer_t0 = rfl(defer_t0); defer_leaf = rfl(defer_leaf); grow_shift = rfl(grow_shift); smax = rfl(smax);
+    defer_t0 = rfl(defer_t0); defer_leaf = rfl(defer_leaf); grow_shift = rfl(grow_shift);
     int icnt = rfl(W.item_n); const int icap = rfl((int)item_cap), inst = rfl(W.cur_blas); item_base = rfl64(item_base);
     const float eps = RAY_EPSILON;
     const unsigned long long nodes = rfl64((unsigned long long)nodes4), tris = rfl64((unsigned long long)W.tris);
@@ -671,16 +671,12 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
         "s_cselect_b32 s91, %[tld], %[t0d]\n\t"
         "s_add_i32 s90, s90, s91\n\t"
         "s_cmp_le_u32 s89, s90\n\t"
-        "s_cbranch_scc0 PKB_NODEFER_%=\n\t"
-        "s_lshr_b32 s91, %[first], 24\n\t"                 // inner nodes carry min(255, triangles below) in the top byte of `first`:
-        "s_cmp_le_u32 s91, %[smax]\n\t"                    // only subtrees up to smax triangles are handed over (255 = any)
         "s_cbranch_scc1 PKB_DEFER_%=\n\t"
         "PKB_NODEFER_%=:\n\t"
         "s_cmp_lg_u32 %[cnt], 0\n\t"
         "s_cbranch_scc1 PKB_LEAF_%=\n\t"
         // ---------------- inner node: four slots ----------------
-        "s_and_b32 s88, %[first], 0xffffff\n\t"
-        "s_lshl_b32 s88, s88, 6\n\t"
+        "s_lshl_b32 s88, %[first], 6\n\t"
         "s_load_dwordx16 s[48:63], s[94:95], s88\n\t"
         "s_add_u32 s88, s88, 64\n\t"
         "s_load_dwordx16 s[64:79], s[94:95], s88\n\t"
@@ -738,9 +734,8 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
         "s_add_u32 s88, %[icnt], 64\n\t"
         "s_cmp_gt_u32 s88, %[icap]\n\t"
         "s_cbranch_scc1 PKB_NODEFER_%=\n\t"                 // chunk full: the packet keeps the node
-        "s_and_b32 s88, %[first], 0xffffff\n\t"
         "s_lshl_b32 s89, %[cnt], 24\n\t"
-        "s_or_b32 s89, s89, s88\n\t"
+        "s_or_b32 s89, s89, %[first]\n\t"
         "s_mov_b64 s[92:93], %[m]\n\t"
         "s_mov_b64 s[84:85], exec\n\t"
         "s_mov_b64 exec, %[m]\n\t"
@@ -773,9 +768,8 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
         "s_and_b64 s[84:85], vcc, %[m]\n\t"
         "s_cmp_lg_u64 s[84:85], 0\n\t"
         "s_cbranch_scc1 PKB_NODEFER_%=\n\t"
-        "s_and_b32 s88, %[first], 0xffffff\n\t"
         "s_lshl_b32 s89, %[cnt], 24\n\t"
-        "s_or_b32 s89, s89, s88\n\t"
+        "s_or_b32 s89, s89, %[first]\n\t"
         "s_mov_b64 s[84:85], exec\n\t"
         "s_mov_b64 exec, %[m]\n\t"
         "v_lshl_add_u32 %[t0], %[psp], 8, %[llds]\n\t"
@@ -817,7 +811,7 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
           [oxy] "v"(W.ray.o_xy), [ozz] "v"(W.ray.o_zz), [ixy] "v"(W.ray.i_xy), [izz] "v"(W.ray.i_zz), [tcur] "v"(W.ray.tcur),
           [ox] "v"(W.ray.o_xy.x), [oy] "v"(W.ray.o_xy.y), [oz] "v"(W.ray.o_zz.x), [dx] "v"(W.ray.d.x), [dy] "v"(W.ray.d.y), [dz] "v"(W.ray.d.z),
           [eps] "s"(eps), [t0d] "s"(defer_t0), [tld] "s"(defer_leaf), [gsh] "s"(grow_shift), [llds] "v"(lane_lds),
-          [icap] "s"(icap), [ibase] "s"(item_base), [inst] "s"(inst), [slot] "v"(slot), [smax] "s"(smax)
+          [icap] "s"(icap), [ibase] "s"(item_base), [inst] "s"(inst), [slot] "v"(slot)
         : "vcc", "scc", "m0", "memory",
           "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
           "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
@@ -827,7 +821,7 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
     if (err) W.err = 1;
 }
 
-struct PkHybrid { int * stk; float * stk_key; uint32_t lane_lds; int * spill; float * spill_key; int spill_stride; int * fifo; int fifo_stride; int t0, t_leaf, grow; uint32_t item_cap; unsigned long long item_base; int item_smax; };
+struct PkHybrid { int * stk; float * stk_key; uint32_t lane_lds; int * spill; float * spill_key; int spill_stride; int * fifo; int fifo_stride; int t0, t_leaf, grow; uint32_t item_cap; unsigned long long item_base; };
 
 // ---- hybrid any-hit walk, per-lane phase -----------------------------------------------------------------------------------------
 // Walks the subtrees the packet walk handed to the lanes' private stacks (entries are nodes that already passed the lane's slab test,
@@ -933,8 +927,8 @@ RTX_D void pk_lane_phase_any4(PkWalk & W, const int lane, const uint32_t lane_ld
             const float4 a0 = gld(nodes4, base), a1 = gld(nodes4, base + 1), b0 = gld(nodes4, base + 2), b1 = gld(nodes4, base + 3);
             const float4 c0 = gld(nodes4, base + 4), c1 = gld(nodes4, base + 5), d0 = gld(nodes4, base + 6), d1 = gld(nodes4, base + 7);
             const bool p0 = pk_slab<true>(a0, a1, W.ray), p1 = pk_slab<true>(b0, b1, W.ray), p2 = pk_slab<true>(c0, c1, W.ray), p3 = pk_slab<true>(d0, d1, W.ray);
-            const int e1 = (int)(((uint32_t)as_i(b1.w) << 24) | ((uint32_t)as_i(b1.z) & 0x00ffffffu)), e2 = (int)(((uint32_t)as_i(c1.w) << 24) | ((uint32_t)as_i(c1.z) & 0x00ffffffu));
-            const int e3 = (int)(((uint32_t)as_i(d1.w) << 24) | ((uint32_t)as_i(d1.z) & 0x00ffffffu));
+            const int e1 = (int)(((uint32_t)as_i(b1.w) << 24) | (uint32_t)as_i(b1.z)), e2 = (int)(((uint32_t)as_i(c1.w) << 24) | (uint32_t)as_i(c1.z));
+            const int e3 = (int)(((uint32_t)as_i(d1.w) << 24) | (uint32_t)as_i(d1.z));
             // slot k is pushed when it passes and a lower slot passes too (that one is walked first)
             const bool q3 = p3 & (p0 | p1 | p2), q2 = p2 & (p0 | p1), q1 = p1 & p0;
             if (psp + 3 <= RTX_PK_PRIV) {
@@ -943,7 +937,7 @@ RTX_D void pk_lane_phase_any4(PkWalk & W, const int lane, const uint32_t lane_ld
                 if (q1) { stk[psp * RTX_WAVE] = e1; psp++; }
             } else { if (q3) push(e3); if (q2) push(e2); if (q1) push(e1); }
             have_cur = p0 | p1 | p2 | p3;
-            cur_first = (p0 ? as_i(a1.z) : (p1 ? as_i(b1.z) : (p2 ? as_i(c1.z) : as_i(d1.z)))) & 0x00ffffff;      // without the size byte
+            cur_first = p0 ? as_i(a1.z) : (p1 ? as_i(b1.z) : (p2 ? as_i(c1.z) : as_i(d1.z)));
             cur_cnt   = p0 ? as_i(a1.w) : (p1 ? as_i(b1.w) : (p2 ? as_i(c1.w) : as_i(d1.w)));
         }
         if (live && have_cur && cur_cnt > 0) {
@@ -1212,12 +1206,11 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
                 // the whole BLAS walk, hand-scheduled (returns with m == 0), then the per-lane phase over what it deferred
                 PK_T0();
                 W.psp = 0;
-                if ((SPLIT || B.pk4_nodes) && (W.cur_cnt & 0x3fffffff) == 0) W.cur_first |= (int)0xff000000u;      // an inner root counts as a big subtree (the size byte of `first`)
                 if (SPLIT) {                                         // split walk (every mesh has 4-wide records): deferred nodes become items, no per-lane phase here
-                    pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.t_leaf, H.grow, H.item_cap, H.item_base, W.item_slot, H.item_smax);
+                    pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.t_leaf, H.grow, H.item_cap, H.item_base, W.item_slot);
                     PK_T1(1);
                 } else if (B.pk4_nodes) {                            // nested boxes: the 4-wide records
-                    pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.t_leaf, H.grow, 0u, 0ull, 0u, 255);
+                    pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.t_leaf, H.grow, 0u, 0ull, 0u);
                     PK_T1(1);
                     if (W.alive != 0ull && __ballot(W.psp > 0) != 0ull) { PK_T0(); pk_lane_phase_any4(W, lane, H.lane_lds, H.spill, H.spill_stride, RTX_GPTR(B.pk4_nodes), RTX_GPTR(B.tri_hot)); PK_T1(2); }
                 } else {
@@ -1260,7 +1253,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
         H.fifo = q.pk_fifo + gt; H.fifo_stride = q.spill_threads;
     }
     H.t0 = ANY ? q.pk_defer_t0 : q.pk_defer_t0_closest; H.t_leaf = q.pk_defer_leaf; H.grow = q.pk_defer_grow;
-    H.item_cap = 0; H.item_base = 0ull; H.item_smax = q.pk_item_smax;
+    H.item_cap = 0; H.item_base = 0ull;
     const uint32_t gwave  = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
     const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE);
 
@@ -1492,11 +1485,11 @@ void k_items(const DevScene sc, const DevQueues q, const int n_chunks, const int
             const float4 a0 = gld(nodes4, base), a1 = gld(nodes4, base + 1), b0 = gld(nodes4, base + 2), b1 = gld(nodes4, base + 3);
             const float4 c0 = gld(nodes4, base + 4), c1 = gld(nodes4, base + 5), d0 = gld(nodes4, base + 6), d1 = gld(nodes4, base + 7);
             const bool p0 = pk_slab<true>(a0, a1, ray), p1 = pk_slab<true>(b0, b1, ray), p2 = pk_slab<true>(c0, c1, ray), p3 = pk_slab<true>(d0, d1, ray);
-            if (p3 & (p0 | p1 | p2)) push((int)(((uint32_t)as_i(d1.w) << 24) | ((uint32_t)as_i(d1.z) & 0x00ffffffu)));
-            if (p2 & (p0 | p1))      push((int)(((uint32_t)as_i(c1.w) << 24) | ((uint32_t)as_i(c1.z) & 0x00ffffffu)));
-            if (p1 & p0)             push((int)(((uint32_t)as_i(b1.w) << 24) | ((uint32_t)as_i(b1.z) & 0x00ffffffu)));
+            if (p3 & (p0 | p1 | p2)) push((int)(((uint32_t)as_i(d1.w) << 24) | (uint32_t)as_i(d1.z)));
+            if (p2 & (p0 | p1))      push((int)(((uint32_t)as_i(c1.w) << 24) | (uint32_t)as_i(c1.z)));
+            if (p1 & p0)             push((int)(((uint32_t)as_i(b1.w) << 24) | (uint32_t)as_i(b1.z)));
             have_cur = p0 | p1 | p2 | p3;
-            cur_first = (p0 ? as_i(a1.z) : (p1 ? as_i(b1.z) : (p2 ? as_i(c1.z) : as_i(d1.z)))) & 0x00ffffff;
+            cur_first = p0 ? as_i(a1.z) : (p1 ? as_i(b1.z) : (p2 ? as_i(c1.z) : as_i(d1.z)));
             cur_cnt   = p0 ? as_i(a1.w) : (p1 ? as_i(b1.w) : (p2 ? as_i(c1.w) : as_i(d1.w)));
         }
         if (busy && have_cur && cur_cnt > 0) {

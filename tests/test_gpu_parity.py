@@ -327,3 +327,17 @@ def test_per_level_kernel_selection_changes_nothing(api, name, lane_from, monkey
     for mode in ({}, {"serial": True}):
         cmp = util.compare_to_golden(r.render(**mode), g)
         assert cmp["stats_equal"] and cmp["max_abs"] == 0.0 and cmp["n_diff_pixels"] == 0 and cmp["packed_mismatch"] == 0, (mode, cmp)
+
+
+@pytest.mark.parametrize("split", ["0", "2048", "64"])
+@pytest.mark.parametrize("name", ["monkey_small", "materials_aniso", "dynamic", "tori16"])
+def test_split_shadow_walk_changes_nothing(api, name, split, monkeypatch):
+    """RTX_PK_SPLIT: the shadow-ray packet kernel hands the nodes few lanes want to a second kernel as 48-byte items (csrc/rtx_packet.h
+    k_items) instead of walking them in its own per-lane phase.  Off, on, and on with chunks so small (64 items) that most hand-overs are
+    refused and the packet keeps the node: always the reference's frame, in both launch shapes."""
+    monkeypatch.setenv("RTX_PK_SPLIT", split)
+    sc, g = util.load_golden(name)
+    r = api.Renderer(sc)
+    for mode in ({}, {"serial": True}, {"serial": True, "cull_dead_shadow_rays": True}):
+        cmp = util.compare_to_golden(r.render(**mode), g)
+        assert cmp["stats_equal"] and cmp["max_abs"] == 0.0 and cmp["n_diff_pixels"] == 0 and cmp["packed_mismatch"] == 0, (mode, cmp)
