@@ -6,7 +6,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 NAMES = {"k_packet<true": "k_trace_any", "k_trace_fast<true": "k_trace_any", "k_packet<false": "k_trace_closest", "k_trace_fast<false": "k_trace_closest",
-         "k_shade": "k_shade", "k_resolve": "k_resolve"}
+         "k_items": "k_trace_items", "k_shade": "k_shade", "k_resolve": "k_resolve"}
 
 
 def collect(d, counter):
@@ -25,9 +25,9 @@ def collect(d, counter):
 fetch, nf = collect(sys.argv[1], "FETCH_SIZE")
 write, nw = collect(sys.argv[2], "WRITE_SIZE")
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 --no-extras` "
-               "(3 frames in flight, one stream per frame: 4 closest-hit launches, ONE shadow-ray launch, 4 shade, 4 resolve per frame), averaged per launch; "
+               "(3 frames in flight, one stream per frame: 4 closest-hit launches, ONE shadow-ray packet launch + its item launch, 4 shade, 4 resolve per frame), averaged per launch; "
                "bytes = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, both reported in KB; Infinity-Cache hits included (upper bound on HBM traffic)"}
-for k in ("k_trace_any", "k_trace_closest", "k_shade", "k_resolve"):
+for k in ("k_trace_any", "k_trace_items", "k_trace_closest", "k_shade", "k_resolve"):
     if nf[k] and nw[k]:
         f, w = fetch[k] / nf[k], write[k] / nw[k]
         out[k + "_bytes_per_launch"] = int((2 * f + w) * 1024)
