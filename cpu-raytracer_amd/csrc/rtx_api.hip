@@ -274,13 +274,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     { int ib = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&ib, k_items, RTX_PK_BLOCK, 0); c->item_blocks = c->n_cu * (ib > 0 ? ib : 4);
       if (const char * e = getenv("RTX_ITEM_GRID")) { const double f = atof(e); if (f > 0.0) c->item_blocks = (int)(c->n_cu * f); } }
     c->split_items = 2048; if (const char * e = getenv("RTX_PK_SPLIT")) c->split_items = atoi(e);       // items per chunk of the split shadow-ray walk (0 = off)
-    c->q.pk_items = nullptr; c->q.pk_item_count = nullptr; c->q.pk_item_cap = 0;
-    if (!rc && c->split_items > 0) {
-        const size_t chunks = (size_t)c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE);
-        rc = ensure(c, c->d_pk_items, chunks * (size_t)c->split_items * 48);
-        if (!rc) rc = ensure(c, c->d_pk_item_count, chunks * 4);
-        if (!rc) { hipMemset(c->d_pk_item_count.p, 0, chunks * 4); c->q.pk_items = (uint4 *)c->d_pk_items.p; c->q.pk_item_count = (uint32_t *)c->d_pk_item_count.p; c->q.pk_item_cap = c->split_items; }
-    }
+    c->q.pk_items = nullptr; c->q.pk_item_count = nullptr; c->q.pk_item_cap = 0;      // sized per render call (render_tiles_impl)
     if (rc) { rtx_destroy(c); return rc; }
     *out_ctx = c;
     return RTX_OK;
@@ -588,7 +582,7 @@ __global__ void k_begin_batch(DevCounters * ctr, uint32_t * pk_heads, uint32_t p
         for (int k = i; k < (int)(sizeof(DevCounters) / 4); k += blockDim.x) w[k] = 0u;
         __syncthreads();
     }
-    if (i <= RTX_MAX_LEVELS) { ctr->ray_count[i] = (i == 0) ? primary_slots : 0u; ctr->lit_count[i] = 0u; ctr->fetch_closest[i] = closest_threads; ctr->fetch_any[i] = any_threads; }
+    if (i <= RTX_MAX_LEVELS) { ctr->ray_count[i] = (i == 0) ? primary_slots : 0u; ctr->item_max[i] = 0u; ctr->fetch_closest[i] = closest_threads; ctr->fetch_any[i] = any_threads; }
     // packet-queue heads (rtx_packet.h): head c of a launch hands out packets k * 8 + c; the static first round (wave w takes packet w)
     // has already covered k < waves / 8 of every head
     for (int k = i; k < 2 * (RTX_MAX_LEVELS + 1) * RTX_PK_CLASSES; k += blockDim.x)
@@ -696,18 +690,27 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
             });
         };
         // split shadow-ray walk (RTX_PK_SPLIT): the items the packet launch emitted, one per lane
+        // item chunks of the split shadow-ray walk: one per wave of the packet launch, sized from the batch (≈0.3 items per shadow ray in the
+        // cfg3 frame, the fullest chunk 3x the average; a full chunk only makes the packet keep its nodes): 4x the expected average, a power of two
+        if (c->split_items > 0 && sc.light_count > 0) {
+            const size_t chunks = (size_t)c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE);
+            const double expect = 0.45 * (double)q.primary_slots * sc.light_count / (double)chunks;
+            int cap = c->split_items; while (cap < 4.0 * expect && cap < (1 << 16)) cap *= 2;
+            if (ensure(c, c->d_pk_items, chunks * (size_t)cap * 48) == 0 && ensure(c, c->d_pk_item_count, chunks * 4) == 0) {
+                q.pk_items = (uint4 *)c->d_pk_items.p; q.pk_item_count = (uint32_t *)c->d_pk_item_count.p; q.pk_item_cap = cap;
+            }
+        }
         bool split = q.pk_items != nullptr;                   // needs 4-wide records for every mesh
         for (size_t b = 0; b < c->h_blas.size(); b++) if (c->h_blas[b].nodes && !c->h_blas[b].pk4_nodes) split = false;
         if (!split) { q.pk_items = nullptr; q.pk_item_count = nullptr; q.pk_item_cap = 0; }
-        auto launch_items = [&](hipStream_t st) {
+        auto launch_items = [&](hipStream_t st, int lo) {
             if (!split) return;
-            const int batches = (q.pk_item_cap + RTX_WAVE - 1) / RTX_WAVE, chunks = c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE);
-            launch_timed(c, "k_trace_items", st, [&] { hipLaunchKernelGGL(k_items, dim3(c->item_blocks), dim3(RTX_PK_BLOCK), 0, st, sc, q, chunks, batches); });
+            launch_timed(c, "k_trace_items", st, [&] { hipLaunchKernelGGL(k_items, dim3(c->item_blocks), dim3(RTX_PK_BLOCK), 0, st, sc, q, c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE), lo); });
         };
         auto launch_any = [&](hipStream_t st, int lo, int hi) {
             if (!count_work && !simple && !lane && !pstat && hi >= lane_from) {      // levels lo .. lane_from-1 by packets, the rest per lane
                 if (lo < lane_from) { launch_timed(c, "k_trace_any", st, [&] { if (split) hipLaunchKernelGGL((k_packet<true, false, true>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, lane_from - 1);
-                                                                                 else       hipLaunchKernelGGL((k_packet<true, false>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, lane_from - 1); }); launch_items(st); }
+                                                                                 else       hipLaunchKernelGGL((k_packet<true, false>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, lane_from - 1); }); launch_items(st, lo); }
                 const int l0 = lo > lane_from ? lo : lane_from;
                 launch_timed(c, "k_trace_any", st, [&] { hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, st, sc, q, l0, hi); });
                 return;
@@ -720,7 +723,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
                 else if (split)     hipLaunchKernelGGL((k_packet<true, false, true>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, hi);
                 else                hipLaunchKernelGGL((k_packet<true, false>), dim3(c->pk_blocks_any), dim3(RTX_PK_BLOCK), 0, st, sc, q, lo, hi);
             });
-            if (!count_work && !simple && !lane && !pstat) launch_items(st);
+            if (!count_work && !simple && !lane && !pstat) launch_items(st, lo);
         };
         for (int level = 0; level < levels; level++) {
             launch_closest(level);

@@ -56,7 +56,7 @@ struct DevTexture {
 
 struct DevCounters {
     uint32_t ray_count[RTX_MAX_LEVELS + 1];       // rays queued per level (level 0 = primary slots)
-    uint32_t lit_count[RTX_MAX_LEVELS + 1];       // lit hits per level (shadow-slot rank allocator)
+    uint32_t item_max[RTX_MAX_LEVELS + 1];        // split shadow-ray walk: the fullest item chunk of the packet launch that started at this level (k_items reads it)
     uint32_t fetch_closest[RTX_MAX_LEVELS + 1];   // dynamic-fetch heads of the persistent trace kernels
     uint32_t fetch_any[RTX_MAX_LEVELS + 1];
     uint32_t error_flags;                         // bit0: traversal stack overflow, bit1: queue overflow

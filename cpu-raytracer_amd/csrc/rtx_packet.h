@@ -1406,7 +1406,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
     W.prof[8] = (1ull << 62) - pk_k0_;                           // first start (max of the complement)
     if (lane == 0) for (int i = 0; i < 10; i++) { if (i == 4 || i == 5 || i == 7 || i == 8 || i == 9) atomicMax(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); else atomicAdd(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); }
 #endif
-    if (ANY && SPLIT && q.pk_items && lane == 0) q.pk_item_count[gwave] = (uint32_t)W.item_n;
+    if (ANY && SPLIT && q.pk_items && lane == 0) { q.pk_item_count[gwave] = (uint32_t)W.item_n; if ((uint32_t)W.item_n > __hip_atomic_load(&ctr->item_max[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ctr->item_max[level], (uint32_t)W.item_n); }      // few waves raise the maximum: one counter sustains only ~90 atomics/us
     if (W.err) { if (lane == 0) atomicOr(&ctr->error_flags, ERR_STACK_OVERFLOW); }
     if (PSTAT && lane == 0) {
         atomicAdd(&ctr->work[15 + PKS_PACKETS], st_packets); atomicAdd(&ctr->work[15 + PKS_PAIR_STEPS], W.st_pairs);
@@ -1419,7 +1419,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
 // An item = (model-space origin, max distance) (model-space direction, ray slot) (node that passed the ray's test, mesh): 48 bytes, written by
 // the packet walk where few lanes wanted a node.  Most are tiny (2.5 loop iterations on average in the cfg3 frame, a few take a hundred) and
 // there are millions of them.  Unit of work = 64 consecutive items of one chunk (chunk c = what wave c of the packet launch emitted); units are
-// numbered batch-major (unit u = batch u / chunks of chunk u % chunks) and dealt round-robin to the waves of a persistent grid, so every
+// numbered batch-major (unit u = batch u / chunks of chunk u % chunks, as many batches as the fullest chunk has) and dealt round-robin to the waves of a persistent grid, so every
 // wave gets the same mix of full, partial and empty units without any queue.  Inside a wave, a lane that finishes its item takes the next
 // one of the wave's units at once (ballot + prefix rank): a long item keeps one lane busy, not 64.  A lane walks its item's subtree over the
 // 4-wide records with a private stack (LDS, then scratch); a hit sets the ray's occlusion flag (the packet kernel wrote 0 or 1 before); a
@@ -1429,10 +1429,11 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
 #define RTX_ITEM_WAVES 6
 #endif
 __global__ __launch_bounds__(RTX_PK_BLOCK, RTX_ITEM_WAVES)
-void k_items(const DevScene sc, const DevQueues q, const int n_chunks, const int n_batches) {
+void k_items(const DevScene sc, const DevQueues q, const int n_chunks, const int level) {
     __shared__ int s_stk[RTX_ITEM_LDS][RTX_PK_BLOCK];
     const uint32_t gwave = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
-    const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE), units = (uint32_t)n_chunks * (uint32_t)n_batches;
+    const uint32_t n_batches = ((uint32_t)rfl((int)q.counters->item_max[level]) + 63u) >> 6;      // the fullest chunk of the packet launch bounds the units
+    const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE), units = (uint32_t)n_chunks * n_batches;
     int ovf[RTX_PK4_MAX_NEED + 4];                                                   // stack entries beyond the LDS ones (scratch; rare)
 #ifdef RTX_ITEM_STATS
     unsigned long long st_iters = 0, st_busy = 0, st_batches = 0, st_items = 0;
