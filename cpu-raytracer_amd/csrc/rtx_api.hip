@@ -273,7 +273,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     if (!rc) rc = ensure(c, c->d_pk_fifo, (size_t)c->q.spill_threads * RTX_PK_FIFO * 4);
     { int ib = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&ib, k_items, RTX_PK_BLOCK, 0); c->item_blocks = c->n_cu * (ib > 0 ? ib : 4);
       if (const char * e = getenv("RTX_ITEM_GRID")) { const double f = atof(e); if (f > 0.0) c->item_blocks = (int)(c->n_cu * f); } }
-    c->split_items = 2048; if (const char * e = getenv("RTX_PK_SPLIT")) c->split_items = atoi(e);       // items per chunk of the split shadow-ray walk (0 = off)
+    c->split_items = 256; if (const char * e = getenv("RTX_PK_SPLIT")) c->split_items = atoi(e);       // split shadow-ray walk: 0 = off, else the smallest item chunk (sized per batch, see render_tiles_impl)
     c->q.pk_items = nullptr; c->q.pk_item_count = nullptr; c->q.pk_item_cap = 0;      // sized per render call (render_tiles_impl)
     if (rc) { rtx_destroy(c); return rc; }
     *out_ctx = c;
@@ -286,7 +286,7 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto & v : c->blas_allocs) for (void * p : v) hipFree(p);
     for (void * p : c->tex_allocs) if (p) hipFree(p);
-    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->d_frame, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads, &c->d_pk_fifo, &c->d_stats_partial };
+    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->d_frame, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads, &c->d_pk_fifo, &c->d_pk_items, &c->d_pk_item_count, &c->d_stats_partial };
     for (DevBuf * b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf & b : c->qb) if (b.p) hipFree(b.p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);

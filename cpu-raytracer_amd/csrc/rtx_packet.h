@@ -1425,12 +1425,16 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
 // 4-wide records with a private stack (LDS, then scratch); a hit sets the ray's occlusion flag (the packet kernel wrote 0 or 1 before); a
 // ray already flagged skips its items.
 #define RTX_ITEM_LDS 8
+#define RTX_ITEM_MESHES 32
 #ifndef RTX_ITEM_WAVES
 #define RTX_ITEM_WAVES 6
 #endif
 __global__ __launch_bounds__(RTX_PK_BLOCK, RTX_ITEM_WAVES)
 void k_items(const DevScene sc, const DevQueues q, const int n_chunks, const int level) {
     __shared__ int s_stk[RTX_ITEM_LDS][RTX_PK_BLOCK];
+    __shared__ unsigned long long s_mesh[RTX_ITEM_MESHES][2];          // (4-wide records, triangles) of the first meshes: a hand-over costs no dependent global fetch for them
+    for (int b = threadIdx.x; b < RTX_ITEM_MESHES && b < sc.blas_count; b += blockDim.x) { s_mesh[b][0] = (unsigned long long)sc.blas[b].pk4_nodes; s_mesh[b][1] = (unsigned long long)sc.blas[b].tri_hot; }
+    __syncthreads();
     const uint32_t gwave = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
     const uint32_t n_batches = ((uint32_t)rfl((int)q.counters->item_max[level]) + 63u) >> 6;      // the fullest chunk of the packet launch bounds the units
     const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE), units = (uint32_t)n_chunks * n_batches;
@@ -1464,8 +1468,8 @@ void k_items(const DevScene sc, const DevQueues q, const int n_chunks, const int
                 const uint4 * const it = items + 3 * (size_t)(pos + rank);
                 const uint4 q0 = it[0], q1 = it[1]; const uint2 q2 = *(const uint2 *)(it + 2);
                 slot = q1.w;
-                const DevBlas & B = sc.blas[q2.y];
-                nodes4 = RTX_GPTR(B.pk4_nodes); tris = RTX_GPTR(B.tri_hot);
+                if (q2.y < RTX_ITEM_MESHES) { nodes4 = (rtx_gptr)s_mesh[q2.y][0]; tris = (rtx_gptr)s_mesh[q2.y][1]; }
+                else { const DevBlas & B = sc.blas[q2.y]; nodes4 = RTX_GPTR(B.pk4_nodes); tris = RTX_GPTR(B.tri_hot); }
                 co = V3(as_f((int)q0.x), as_f((int)q0.y), as_f((int)q0.z)); cd = V3(as_f((int)q1.x), as_f((int)q1.y), as_f((int)q1.z));
                 pk_set_ray(ray, co, cd, vrcp(cd)); ray.tcur = as_f((int)q0.w);        // vrcp as at the instance entry of the packet walk: the same bits
                 cur_first = (int)(q2.x & 0x00ffffffu); cur_cnt = (int)(q2.x >> 24); have_cur = true; psp = 0;
