@@ -678,8 +678,13 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         // 0.19 / 0.14 ms) while the packet kernels win everywhere else (tools/perlevel3.py).  Both produce the same bits.
         // With hundreds of instances the closest-hit reflection rays of level 1 already prefer the per-lane kernel (tools/many_instances.py:
         // 144 instances 0.52 vs 0.40 ms, 576 instances 0.70 vs 0.39 ms), the shadow rays of level 1 do not (0.48 vs 0.8 ms).
-        const int lane_from = c->lane_from_level >= 0 ? c->lane_from_level : (sc.instance_count > 1 ? 2 : RTX_MAX_LEVELS + 1);
+        int lane_from = c->lane_from_level >= 0 ? c->lane_from_level : (sc.instance_count > 1 ? 2 : RTX_MAX_LEVELS + 1);
         const int lane_from_closest = c->lane_from_level >= 0 ? c->lane_from_level : (sc.instance_count > 64 ? 1 : lane_from);
+        // With the split walk a shadow-ray packet that enters an instance with few lanes hands the whole visit over as items, and ONE packet
+        // launch for all levels beats a packet launch + a per-lane launch at every instance count measured (tools/any_rule.sh: 16 / 144 / 576
+        // instances 1.54 / 2.24 / 3.01 vs 1.66 / 2.41 / 3.05 ms per frame, cfg5 2.32 vs 2.42): shadow rays then stay with the packets
+        if (c->lane_from_level < 0 && c->split_items > 0 && sc.light_count > 0) { bool all_wide = true; for (size_t b = 0; b < c->h_blas.size(); b++) if (c->h_blas[b].nodes && !c->h_blas[b].pk4_nodes) all_wide = false; if (all_wide) lane_from = RTX_MAX_LEVELS + 1; }
+        if (const char * e = getenv("RTX_LANE_FROM_LEVEL_ANY")) lane_from = atoi(e);        // shadow rays only (A/B runs)
         auto launch_closest = [&](int level) {
             launch_timed(c, "k_trace_closest", c->stream, [&] {
                 if (count_work)     hipLaunchKernelGGL((k_trace<false, true>),   dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
