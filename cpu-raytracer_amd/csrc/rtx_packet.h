@@ -1318,7 +1318,8 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
             uint32_t local = pk; int d = level;
             uint32_t lit_n = shadow_slots(ctr, q, d), seg = (lit_n + 63u) >> 6;
             while (d < level_hi && local >= seg * (uint32_t)nL) { local -= seg * (uint32_t)nL; d++; lit_n = shadow_slots(ctr, q, d); seg = (lit_n + 63u) >> 6; }
-            const uint32_t light = local / seg, rank = (local - light * seg) * 64u + (uint32_t)lane;
+            uint32_t light = 0; while (local >= seg && light + 1u < (uint32_t)nL) { local -= seg; light++; }      // wave-uniform, at most light_count - 1 rounds: no integer division on the VALU
+            const uint32_t rank = local * 64u + (uint32_t)lane;
             W.valid = rank < lit_n && shadow_slot_is_lit(q, d, rank);      // the shadow rays of the 64 rays of the level's packet `local % seg`
             if (W.valid) {
                 out_slot = (uint32_t)q.shadow_base[d] + light * (uint32_t)q.level_cap[d] + rank;
@@ -1375,7 +1376,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
             W.sp = 0; W.floor_sp = -1; W.cur_inst = 0; W.depth = 0; W.cur_idx = 0;
             {   // TLAS root: pushed, popped and tested by the reference (TopLevelBVH.cpp:58-67)
                 const float4 na = sld(W.nodes, 0), nb = sld(W.nodes, 1);
-                W.m = __ballot(pk_slab<false>(na, nb, W.ray)) & W.alive;
+                W.m = (nanfree_world ? __ballot(pk_slab<true>(na, nb, W.ray)) : __ballot(pk_slab<false>(na, nb, W.ray))) & W.alive;
                 W.cur_first = as_i(nb.z); W.cur_cnt = as_i(nb.w);
             }
             PK_T1(0);
