@@ -1207,7 +1207,11 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
                 PK_T0();
                 W.psp = 0;
                 if (SPLIT) {                                         // split walk (every mesh has 4-wide records): deferred nodes become items, no per-lane phase here
+#ifdef RTX_PK_SKIPWALK
+                    W.m = 0ull;                                      // measurement only: everything but the BLAS walk
+#else
                     pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.t_leaf, H.grow, H.item_cap, H.item_base, W.item_slot);
+#endif
                     PK_T1(1);
                 } else if (B.pk4_nodes) {                            // nested boxes: the 4-wide records
                     pk_blas_any_asm4(W, pk_cptr(B.pk4_nodes), H.lane_lds, H.t0, H.t_leaf, H.grow, 0u, 0ull, 0u);
