@@ -181,3 +181,25 @@ def test_single_leaf_mesh(api, name, k):
         out = r.render(**mode)
         assert out["stats"] == ref["stats"], mode
         assert util.bit_exact(out["rgb"], ref["rgb"]) and np.array_equal(out["packed"], ref["packed"]), mode
+
+
+def test_group_attach_and_debug_entry_points_refuse_bad_arguments(api):
+    """Status codes instead of faults: rtx_group_attach with a foreign resolution / the base itself / no group, rtx_debug_blas_wide with an
+    unknown mesh id."""
+    import ctypes as C
+    sc, _ = util.load_golden("cube")
+    sc2, _ = util.load_golden("monkey_small")
+    r, r_same, r_other = api.Renderer(sc), api.Renderer(sc), api.Renderer(sc2)
+    r.group_create(0, 1, api.Renderer.group_unique_id())
+    out = C.c_void_p()
+    assert r.lib.rtx_group_attach(r.ctx, r.group, C.byref(out)) == 1              # the base context itself
+    assert r.lib.rtx_group_attach(r_same.ctx, None, C.byref(out)) == 1             # no base group
+    assert r.lib.rtx_group_attach(None, r.group, C.byref(out)) == 1
+    if (sc.width, sc.height) != (sc2.width, sc2.height):
+        assert r.lib.rtx_group_attach(r_other.ctx, r.group, C.byref(out)) == 1     # another resolution
+    r_same.group_attach(r)                                                         # the legitimate case still works afterwards
+    r_same.group_render(); r.group_render()
+    need = C.c_int32(0)
+    assert r.lib.rtx_debug_blas_wide(r.ctx, 99, C.byref(need)) == 1
+    assert r.lib.rtx_debug_blas_wide(r.ctx, 0, None) == 1
+    r_same.group_destroy(); r.group_destroy()
