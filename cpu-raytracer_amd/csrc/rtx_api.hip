@@ -145,6 +145,7 @@ static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, st
     while (!stack.empty()) {
         const int i = stack.back(); stack.pop_back();
         const int cnt = nodes[i].count & 0x3fffffff, f = nodes[i].left_or_first;
+        for (int a = 0; a < 3; a++) if (!(nodes[i].aabb_min[a] <= nodes[i].aabb_max[a])) return false;      // the sign-coherent slab test relies on min <= max
         if (cnt > 0) { if (cnt >= 256) return false; continue; }
         if (f & 1) return false;                                   // records are addressed by left / 2
         if (!inside(f, i) || !inside(f + 1, i)) return false;      // nesting
