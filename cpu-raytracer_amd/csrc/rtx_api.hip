@@ -638,7 +638,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
     if (rc) return rc;
     const int levels = c->cfg.bounces + 1;
     const int stream_blocks = c->n_cu * 8;          // k_resolve (256 threads)
-    int shade_blocks = c->n_cu * 4;                 // k_shade (RTX_SHADE_BLOCK = 384 threads, 2 resident blocks per CU)
+    int shade_blocks = c->n_cu * 4;                 // k_shade (RTX_SHADE_BLOCK = 256 threads, 3 resident blocks per CU at 168 VGPRs)
     if (const char * e = getenv("RTX_SHADE_GRID")) shade_blocks = c->n_cu * atoi(e);
     rc = ensure(c, c->d_stats_partial, (size_t)(RTX_MAX_LEVELS + 1) * shade_blocks * 4 * sizeof(uint32_t));
     if (rc) return rc;

@@ -17,7 +17,8 @@
 #include "rtx_trace.h"
 
 #ifndef RTX_SHADE_BLOCK
-#define RTX_SHADE_BLOCK 384     // 6 waves aggregate their queue appends into ONE global atomic; 2 blocks/CU = 3 waves/SIMD at 168 VGPRs
+#define RTX_SHADE_BLOCK 256     // 4 waves aggregate their queue appends into ONE global atomic; one wave per SIMD: a workgroup finds room beside other frames'
+                                // persistent traversal grids far sooner than a 384-thread one, which needs two 168-VGPR waves on one SIMD (1.39 -> 1.30 ms per frame)
 #endif
 #ifndef RTX_WAVES_SHADE
 #define RTX_WAVES_SHADE 3     // __launch_bounds__ min waves per SIMD for k_shade (168 VGPRs: the kernel needs 169 unconstrained)
