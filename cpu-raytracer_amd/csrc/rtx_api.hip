@@ -257,11 +257,11 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     if (const char * e = getenv("RTX_PK_GRID_SCALE")) { const double f = atof(e); if (f > 0.0) { c->pk_blocks_closest = ((int)(c->pk_blocks_closest * f) + 1) & ~1; c->pk_blocks_any = ((int)(c->pk_blocks_any * f) + 1) & ~1; } }
     if (const char * e = getenv("RTX_PK_GRID_ANY")) { const double f = atof(e); if (f > 0.0) c->pk_blocks_any = ((int)(c->n_cu * f) + 1) & ~1; }          // blocks per CU (A/B runs)
     if (const char * e = getenv("RTX_PK_GRID_CLOSEST")) { const double f = atof(e); if (f > 0.0) c->pk_blocks_closest = ((int)(c->n_cu * f) + 1) & ~1; }
-    int max_blocks = c->trace_blocks_closest > c->trace_blocks_any ? c->trace_blocks_closest : c->trace_blocks_any;
-    if (c->trace_blocks_count > max_blocks) max_blocks = c->trace_blocks_count;
-    if (c->pk_blocks_any > max_blocks) max_blocks = c->pk_blocks_any;       // the packet kernels' per-lane phase spills there too
-    if (c->pk_blocks_closest > max_blocks) max_blocks = c->pk_blocks_closest;
-    { int ib = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&ib, k_items, RTX_PK_BLOCK, 0); if (c->n_cu * (ib > 0 ? ib : 4) * 2 > max_blocks) max_blocks = c->n_cu * (ib > 0 ? ib : 4) * 2; }
+    // threads of the largest launch that indexes the per-thread spill / work-list regions with its global thread id
+    long long max_threads = (long long)(c->trace_blocks_closest > c->trace_blocks_any ? c->trace_blocks_closest : c->trace_blocks_any) * RTX_TRACE_BLOCK;
+    if ((long long)c->trace_blocks_count * RTX_TRACE_BLOCK > max_threads) max_threads = (long long)c->trace_blocks_count * RTX_TRACE_BLOCK;
+    if ((long long)c->pk_blocks_any * RTX_PK_BLOCK > max_threads) max_threads = (long long)c->pk_blocks_any * RTX_PK_BLOCK;       // the packet kernels' per-lane phases spill there too
+    if ((long long)c->pk_blocks_closest * RTX_PK_BLOCK > max_threads) max_threads = (long long)c->pk_blocks_closest * RTX_PK_BLOCK;
     c->q.pk_defer_t0 = 8; if (const char * e = getenv("RTX_PK_DEFER")) c->q.pk_defer_t0 = atoi(e);
     c->q.pk_defer_leaf = c->q.pk_defer_t0 / 2; if (const char * e = getenv("RTX_PK_DEFER_LEAF")) c->q.pk_defer_leaf = atoi(e);
     c->q.pk_defer_t0_closest = 64; if (const char * e = getenv("RTX_PK_DEFER_CLOSEST")) c->q.pk_defer_t0_closest = atoi(e);
@@ -269,10 +269,10 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     if (const char * e = getenv("RTX_PK_WIDE")) c->no_wide = atoi(e) == 0;
     if (const char * e = getenv("RTX_LANE_FROM_LEVEL")) c->lane_from_level = atoi(e);      // per-lane kernels from this level on (default: 2 for multi-instance scenes, never otherwise)      // RTX_PK_WIDE=0: binary shadow-ray walk for every mesh
     c->q.pk_defer_grow = 3; if (const char * e = getenv("RTX_PK_GROW")) c->q.pk_defer_grow = atoi(e);
-    c->q.spill_threads = max_blocks * RTX_TRACE_BLOCK;
+    c->q.spill_threads = (int)max_threads;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast
     if (!rc) rc = ensure(c, c->d_pk_fifo, (size_t)c->q.spill_threads * RTX_PK_FIFO * 4);
-    { int ib = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&ib, k_items, RTX_PK_BLOCK, 0); c->item_blocks = c->n_cu * (ib > 0 ? ib : 4);
+    { int ib = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&ib, k_items, RTX_ITEM_BLOCK, 0); c->item_blocks = c->n_cu * (ib > 0 ? ib : 4);
       if (const char * e = getenv("RTX_ITEM_GRID")) { const double f = atof(e); if (f > 0.0) c->item_blocks = (int)(c->n_cu * f); } }
     c->split_items = 256; if (const char * e = getenv("RTX_PK_SPLIT")) c->split_items = atoi(e);       // split shadow-ray walk: 0 = off, else the smallest item chunk (sized per batch, see render_tiles_impl)
     c->q.pk_items = nullptr; c->q.pk_item_count = nullptr; c->q.pk_item_cap = 0;      // sized per render call (render_tiles_impl)
@@ -711,7 +711,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         if (!split) { q.pk_items = nullptr; q.pk_item_count = nullptr; q.pk_item_cap = 0; }
         auto launch_items = [&](hipStream_t st, int lo) {
             if (!split) return;
-            launch_timed(c, "k_trace_items", st, [&] { hipLaunchKernelGGL(k_items, dim3(c->item_blocks), dim3(RTX_PK_BLOCK), 0, st, sc, q, c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE), lo); });
+            launch_timed(c, "k_trace_items", st, [&] { hipLaunchKernelGGL(k_items, dim3(c->item_blocks), dim3(RTX_ITEM_BLOCK), 0, st, sc, q, c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE), lo); });
         };
         auto launch_any = [&](hipStream_t st, int lo, int hi) {
             if (!count_work && !simple && !lane && !pstat && hi >= lane_from) {      // levels lo .. lane_from-1 by packets, the rest per lane

@@ -37,7 +37,10 @@
 #include "rtx_device.h"
 #include "rtx_trace.h"
 
-#define RTX_PK_BLOCK    256          // 4 independent waves per workgroup
+#ifndef RTX_PK_BLOCK
+#define RTX_PK_BLOCK    64           // the waves of a packet launch are independent: one wave per workgroup finds room beside other frames' kernels
+                                     // soonest (with k_items at 64 too: 1.318 -> 1.275 ms per frame; either one alone: no change)
+#endif
 #define RTX_PK_STACK    64           // packet stack entries per wave = lanes of the stack VGPRs
 #define RTX_PK_CLASSES  8            // packet-queue heads per launch (packet k belongs to head k % 8): spreads the fetch atomics over 8 addresses
 #ifndef RTX_PK_WAVES_ANY
@@ -1496,19 +1499,22 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
 // 4-wide records with a private stack (LDS, then scratch); a hit sets the ray's occlusion flag (the packet kernel wrote 0 or 1 before); a
 // ray already flagged skips its items.
 #define RTX_ITEM_LDS 8
+#ifndef RTX_ITEM_BLOCK
+#define RTX_ITEM_BLOCK 64
+#endif
 #define RTX_ITEM_MESHES 32
 #ifndef RTX_ITEM_WAVES
 #define RTX_ITEM_WAVES 6
 #endif
-__global__ __launch_bounds__(RTX_PK_BLOCK, RTX_ITEM_WAVES)
+__global__ __launch_bounds__(RTX_ITEM_BLOCK, RTX_ITEM_WAVES)
 void k_items(const DevScene sc, const DevQueues q, const int n_chunks, const int level) {
-    __shared__ int s_stk[RTX_ITEM_LDS][RTX_PK_BLOCK];
+    __shared__ int s_stk[RTX_ITEM_LDS][RTX_ITEM_BLOCK];
     __shared__ unsigned long long s_mesh[RTX_ITEM_MESHES][2];          // (4-wide records, triangles) of the first meshes: a hand-over costs no dependent global fetch for them
     for (int b = threadIdx.x; b < RTX_ITEM_MESHES && b < sc.blas_count; b += blockDim.x) { s_mesh[b][0] = (unsigned long long)sc.blas[b].pk4_nodes; s_mesh[b][1] = (unsigned long long)sc.blas[b].tri_hot; }
     __syncthreads();
-    const uint32_t gwave = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
+    const uint32_t gwave = (uint32_t)rfl((int)(blockIdx.x * (RTX_ITEM_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
     const uint32_t n_batches = ((uint32_t)rfl((int)q.counters->item_max[level]) + 63u) >> 6;      // the fullest chunk of the packet launch bounds the units
-    const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE), units = (uint32_t)n_chunks * n_batches;
+    const uint32_t nwaves = gridDim.x * (RTX_ITEM_BLOCK / RTX_WAVE), units = (uint32_t)n_chunks * n_batches;
     int ovf[RTX_PK4_MAX_NEED + 4];                                                   // stack entries beyond the LDS ones (scratch; rare)
 #ifdef RTX_ITEM_STATS
     unsigned long long st_iters = 0, st_busy = 0, st_batches = 0, st_items = 0;
