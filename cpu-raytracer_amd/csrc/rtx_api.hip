@@ -53,7 +53,7 @@ struct rtx_ctx {
     std::vector<void *> tex_allocs;
     int material_count = 0, sky_size = 0;
     // host copies for validate_references(): every id a kernel will follow is checked on the host before anything is launched
-    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true; int lane_from_level = -1; bool no_wide = false; int split_items = 0, item_blocks = 0; DevBuf d_pk_items, d_pk_item_count;
+    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true; int lane_from_level = -1; bool no_wide = false; int split_items = 0, item_blocks = 0, resolve_block = 256; DevBuf d_pk_items, d_pk_item_count;
 
     // per-frame state (rtx_set_frame): ONE device block, filled by one asynchronous copy on the context's stream from a ring of pinned
     // staging buffers — the host never waits for the GPU between frames (cfg5: Scene::update + TLAS rebuild every frame)
@@ -266,6 +266,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->q.pk_defer_leaf = c->q.pk_defer_t0 / 2; if (const char * e = getenv("RTX_PK_DEFER_LEAF")) c->q.pk_defer_leaf = atoi(e);
     c->q.pk_defer_t0_closest = 64; if (const char * e = getenv("RTX_PK_DEFER_CLOSEST")) c->q.pk_defer_t0_closest = atoi(e);
     c->q.pk_order = 1; if (const char * e = getenv("RTX_PK_ORDER")) c->q.pk_order = atoi(e);
+    if (const char * e = getenv("RTX_RESOLVE_BLOCK")) { const int b = atoi(e); if (b == 64 || b == 128 || b == 256) c->resolve_block = b; }      // k_resolve workgroup size (A/B runs)
     if (const char * e = getenv("RTX_PK_WIDE")) c->no_wide = atoi(e) == 0;
     if (const char * e = getenv("RTX_LANE_FROM_LEVEL")) c->lane_from_level = atoi(e);      // per-lane kernels from this level on (default: 2 for multi-instance scenes, never otherwise)      // RTX_PK_WIDE=0: binary shadow-ray walk for every mesh
     c->q.pk_defer_grow = 3; if (const char * e = getenv("RTX_PK_GROW")) c->q.pk_defer_grow = atoi(e);
@@ -757,7 +758,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         }
         if (overlap) { hipEventRecord(c->ev_any_done, c->any_stream); hipStreamWaitEvent(c->stream, c->ev_any_done, 0); }
         for (int level = levels - 1; level >= 0; level--)
-            launch_timed(c, "k_resolve", c->stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(stream_blocks), dim3(256), 0, c->stream, sc, q, level); });
+            launch_timed(c, "k_resolve", c->stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(stream_blocks * (256 / c->resolve_block)), dim3(c->resolve_block), 0, c->stream, sc, q, level); });
     }
     HIP_OK(c, hipGetLastError());
     c->stats_pending = true;
