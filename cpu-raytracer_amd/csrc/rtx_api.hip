@@ -257,6 +257,10 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     if (const char * e = getenv("RTX_PK_GRID_SCALE")) { const double f = atof(e); if (f > 0.0) { c->pk_blocks_closest = ((int)(c->pk_blocks_closest * f) + 1) & ~1; c->pk_blocks_any = ((int)(c->pk_blocks_any * f) + 1) & ~1; } }
     if (const char * e = getenv("RTX_PK_GRID_ANY")) { const double f = atof(e); if (f > 0.0) c->pk_blocks_any = ((int)(c->n_cu * f) + 1) & ~1; }          // blocks per CU (A/B runs)
     if (const char * e = getenv("RTX_PK_GRID_CLOSEST")) { const double f = atof(e); if (f > 0.0) c->pk_blocks_closest = ((int)(c->n_cu * f) + 1) & ~1; }
+    {   // the packet queues hand out packets k * 8 + head after a static first round of one packet per wave: whole rounds only, so waves % 8 == 0
+        const int g = RTX_PK_CLASSES * RTX_WAVE / RTX_PK_BLOCK > 1 ? RTX_PK_CLASSES * RTX_WAVE / RTX_PK_BLOCK : 1;
+        c->pk_blocks_any = (c->pk_blocks_any + g - 1) / g * g; c->pk_blocks_closest = (c->pk_blocks_closest + g - 1) / g * g;
+    }
     // threads of the largest launch that indexes the per-thread spill / work-list regions with its global thread id
     long long max_threads = (long long)(c->trace_blocks_closest > c->trace_blocks_any ? c->trace_blocks_closest : c->trace_blocks_any) * RTX_TRACE_BLOCK;
     if ((long long)c->trace_blocks_count * RTX_TRACE_BLOCK > max_threads) max_threads = (long long)c->trace_blocks_count * RTX_TRACE_BLOCK;
