@@ -9,8 +9,9 @@ anisotropic mip filter).
 
 A "step" is one full frame: rtx_render_tiles over this rank's tiles (inputs resident in HBM) and,
 for N > 1, the RCCL gather of the packed framebuffer tiles to rank 0 (BASELINE configs[3]); the frame
-is fixed as N grows, so scaling is "strong".  Launch: `python bench.py --gpus N --steps K --warmup W`;
-for N > 1 through torch.distributed.run (one process per GPU).
+is fixed as N grows, so scaling is "strong".  Launch: `python bench.py --gpus N --steps K --warmup W` — for N > 1 that process
+starts the N ranks itself (one fresh process per GPU, before anything touches the GPU; `--dry-launch` prints them) — or under
+torch.distributed.run, which sets WORLD_SIZE and makes bench.py one of the ranks.
 """
 import argparse
 import ctypes as C
@@ -150,8 +151,57 @@ def reference_cpu_baseline(args, rays_per_frame, stats):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def launch_plan(n_gpus, argv, master_port=None, env=None):
+    """`python bench.py --gpus N` without a launcher around it: the ranks this process will start, one fresh process per GPU (what
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` would start: same environment variables, rank r on device r).
+    Pure function of its arguments: tests/test_bench_launch.py checks it without a GPU."""
+    env = dict(os.environ if env is None else env)
+    port = int(master_port or env.get("MASTER_PORT") or 29400 + (os.getpid() % 500))
+    plan = []
+    for r in range(n_gpus):
+        e = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_gpus), "LOCAL_WORLD_SIZE": str(n_gpus),
+             "MASTER_ADDR": env.get("MASTER_ADDR", "127.0.0.1"), "MASTER_PORT": str(port),
+             "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}      # dmabuf IPC: RCCL between processes needs it on this driver
+        plan.append({"rank": r, "device": r, "env": e, "argv": [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]})
+    return plan
+
+
+def self_launch(args, argv):
+    """Starts the N ranks as child processes BEFORE this process has touched the GPU (it never does: no torch import, no HIP call), relays
+    rank 0's one JSON line, and exits with the first failing rank's code.  Children are ended by PID, never by pattern."""
+    import subprocess
+    plan = launch_plan(args.gpus, argv)
+    if args.dry_launch:
+        print(json.dumps({"launcher": "bench.py self-launch (one process per GPU, rank r on device r)", "n_gpus": args.gpus, "ranks": plan}))
+        return 0
+    procs = []
+    for p in plan:
+        env = dict(os.environ); env.update(p["env"])
+        procs.append(subprocess.Popen(p["argv"], env=env, stdout=None if p["rank"] == 0 else subprocess.DEVNULL))      # rank 0 prints the line
+    rc, deadline = 0, time.time() + 3000
+    pending = list(procs)
+    while pending:
+        for pr in list(pending):
+            code = pr.poll()
+            if code is None:
+                continue
+            pending.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:          # a rank died: the others would wait for it in the next collective for ever
+                    other.terminate()
+        if time.time() > deadline:
+            for other in pending:
+                other.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no launcher around bench.py: print the ranks / devices / environment it would start, and exit")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
@@ -174,6 +224,13 @@ def main():
     ap.add_argument("--cull", action="store_true", help="time with RTX_RENDER_CULL_DEAD_SHADOW_RAYS as the main figure (default: reported as an extra)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` on its own brings up its N ranks itself; under torch.distributed.run (WORLD_SIZE set) it IS one of the ranks
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
+    if args.dry_launch:
+        print(json.dumps({"launcher": "none needed", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "ranks": []}))
+        return
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,8 +238,12 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from pyrtx import api, host, shard
+    from pyrtx import api, host
 
+    if world != max(args.gpus, 1) and rank == 0:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size wins\n")
+    if torch.cuda.device_count() <= local_rank:          # counting devices does not initialise the GPU
+        sys.exit(f"bench.py: rank {rank} wants GPU {local_rank} but this node shows {torch.cuda.device_count()} (there is no CPU fallback for the render path)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback for the render path)")
     torch.cuda.set_device(local_rank)
@@ -205,9 +266,9 @@ def main():
 
     W, H = sc.width, sc.height
     T = sc.tile_count
-    first, stride, count = shard.shard_args(T, rank, world)     # tile t belongs to GPU t mod N
+    first, stride, count = rank, world, api.group_layout(W, H, world, rank)[2]     # tile t belongs to GPU t mod N
     if args.simulate_ranks > 1 and world == 1:
-        first, stride, count = shard.shard_args(T, 0, args.simulate_ranks)
+        first, stride, count = 0, args.simulate_ranks, api.group_layout(W, H, args.simulate_ranks, 0)[2]
     if args.force_gather and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))

@@ -943,13 +943,14 @@ __global__ void k_debug_sky(const float * sky, int size, const float * dirs, flo
     out3[3 * i] = r.x; out3[3 * i + 1] = r.y; out3[3 * i + 2] = r.z;
 }
 
-// Sky::sample (Sky.cpp:28-68) at n directions
+// which shadow-ray walk an uploaded mesh gets: the stack need of its 4-wide records, or -1 for the binary walk
 extern "C" int rtx_debug_blas_wide(rtx_ctx * c, int32_t blas_id, int32_t * stack_need) {
     if (!c || !stack_need || blas_id < 0 || (size_t)blas_id >= c->h_blas.size() || !c->h_blas[blas_id].nodes) return RTX_ERR_INVALID_ARG;
     *stack_need = c->h_blas[blas_id].pk4_nodes ? c->h_blas[blas_id].pk4_need : -1;
     return RTX_OK;
 }
 
+// Sky::sample (Sky.cpp:28-68) at n directions
 extern "C" int rtx_debug_sky_sample(rtx_ctx * c, const float * dirs3, float * out3, int32_t n) {
     if (!c || !dirs3 || !out3 || n <= 0) return RTX_ERR_INVALID_ARG;
     hipSetDevice(c->cfg.device);
@@ -1018,13 +1019,44 @@ static int group_setup(rtx_group * g) {
     rtx_ctx * c = g->ctx;
     const int tcx = (c->cfg.width + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE, tcy = (c->cfg.height + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE;
     g->tiles_total = tcx * tcy;
-    g->tiles_per_rank = (g->tiles_total + g->world - 1) / g->world;          // padded: every rank sends the same count
-    g->own_tiles = g->rank < g->tiles_total ? (g->tiles_total - g->rank + g->world - 1) / g->world : 0;
+    g->tiles_per_rank = group_tiles_per_rank(g->tiles_total, g->world);      // padded: every rank sends the same count
+    g->own_tiles = group_own_tiles(g->tiles_total, g->world, g->rank);
     hipSetDevice(c->cfg.device);
     int rc = ensure(c, g->send, (size_t)g->tiles_per_rank * 1024 * 4);
     if (!rc && g->rank == 0) rc = ensure(c, g->recv, (size_t)g->world * g->tiles_per_rank * 1024 * 4);
-    if (!rc) hipMemset(g->send.p, 0, (size_t)g->tiles_per_rank * 1024 * 4);
+    // the padding tiles are never written by a render: zero them once, ordered before the first render on the context's own stream
+    if (!rc) HIP_OK(c, hipMemsetAsync(g->send.p, 0, (size_t)g->tiles_per_rank * 1024 * 4, c->stream));
     return rc;
+}
+
+// The partition and the tile-major slot order as plain host functions (no GPU needed): what rank `rank` of `world` renders and where
+// each of its pixels travels in the gather.  They call the very functions the kernels use (rtx_trace.h: group_*, tile_slot_pixel).
+extern "C" int rtx_group_layout(int32_t width, int32_t height, int32_t world, int32_t rank, int32_t * tiles_total, int32_t * tiles_per_rank, int32_t * own_tiles) {
+    if (width <= 0 || height <= 0 || world < 1 || rank < 0 || rank >= world) return RTX_ERR_INVALID_ARG;
+    const int tcx = (width + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE, tcy = (height + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE;
+    if (tiles_total) *tiles_total = tcx * tcy;
+    if (tiles_per_rank) *tiles_per_rank = group_tiles_per_rank(tcx * tcy, world);
+    if (own_tiles) *own_tiles = group_own_tiles(tcx * tcy, world, rank);
+    return RTX_OK;
+}
+
+// pixel_index[i] = raster index (y * width + x) of slot i of the rank's send buffer (tiles_per_rank * 1024 slots), or -1 for padding
+// (clipped pixels of edge tiles, the unused tail when the tiles do not divide evenly).  Rank 0's receive buffer is the concatenation
+// of every rank's send buffer in rank order, which is all k_unswizzle relies on.
+extern "C" int rtx_group_slot_pixels(int32_t width, int32_t height, int32_t world, int32_t rank, int64_t * pixel_index, int64_t capacity) {
+    int32_t total = 0, per_rank = 0, own = 0;
+    const int rc = rtx_group_layout(width, height, world, rank, &total, &per_rank, &own);
+    if (rc) return rc;
+    if (!pixel_index || capacity < (int64_t)per_rank * 1024) return RTX_ERR_INVALID_ARG;
+    const int tcx = (width + RTX_TILE_SIZE - 1) / RTX_TILE_SIZE;
+    for (int k = 0; k < per_rank; k++) {
+        const int tile = group_tile_of(world, rank, k);
+        for (int l = 0; l < 1024; l++) {
+            int px, py; tile_slot_pixel(tile, l, tcx, px, py);
+            pixel_index[(int64_t)k * 1024 + l] = (k < own && tile < total && px < width && py < height) ? (int64_t)py * width + px : -1;
+        }
+    }
+    return RTX_OK;
 }
 
 extern "C" int rtx_group_unique_id(void * id128) {
@@ -1081,14 +1113,15 @@ extern "C" int rtx_group_create_local(rtx_ctx ** contexts, int32_t n, rtx_group 
     for (int i = 0; i < n; i++) { if (!contexts[i]) return RTX_ERR_INVALID_ARG; devs[i] = contexts[i]->cfg.device; out_groups[i] = nullptr; }
     const int e = r->CommInitAll(comms.data(), n, devs.data());
     if (e != 0) { contexts[0]->err = std::string("ncclCommInitAll: ") + r->GetErrorString(e); return RTX_ERR_HIP; }
-    for (int i = 0; i < n; i++) {
+    int rc = RTX_OK;
+    for (int i = 0; i < n; i++) {                                   // every communicator gets an owner first, so that one rollback path frees them all
         rtx_group * g = new rtx_group();
         g->ctx = contexts[i]; g->rank = i; g->world = n; g->hub = new GroupHub(); g->hub->comm = comms[i]; g->hub->device = devs[i];
-        const int rc = group_setup(g);
-        if (rc) { delete g; return rc; }
         out_groups[i] = g;
     }
-    return RTX_OK;
+    for (int i = 0; i < n && !rc; i++) rc = group_setup(out_groups[i]);
+    if (rc) { for (int i = 0; i < n; i++) { rtx_group_destroy(out_groups[i]); out_groups[i] = nullptr; } }
+    return rc;
 }
 
 static int group_render_one(rtx_group * g, uint32_t flags, bool render, bool gather, bool finish) {
@@ -1164,7 +1197,7 @@ extern "C" int rtx_debug_group_loopback(rtx_ctx * c, int32_t world, uint32_t fla
     rtx_group g; g.ctx = c; g.rank = 0; g.world = world;
     int rc = group_setup(&g);
     for (int r = 0; r < world && !rc; r++) {
-        const int own = r < g.tiles_total ? (g.tiles_total - r + world - 1) / world : 0;
+        const int own = group_own_tiles(g.tiles_total, world, r);
         rc = render_tiles_impl(c, r, world, own, flags | RTX_RENDER_SERIAL, (uint32_t *)g.recv.p + (size_t)r * g.tiles_per_rank * 1024);
     }
     if (!rc) {

@@ -571,11 +571,9 @@ void k_unswizzle(const uint32_t * gathered, uint32_t * fb_packed, int world, int
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint32_t rk = i >> 10, l = i & 1023u;
         const int r = (int)(rk / (uint32_t)tiles_per_rank), k = (int)(rk % (uint32_t)tiles_per_rank);
-        const int tile = r + k * world;                                   // WorkerThread.cpp:57-61 numbering, tile t belongs to GPU t mod N
+        const int tile = group_tile_of(world, r, k);                      // WorkerThread.cpp:57-61 numbering, tile t belongs to GPU t mod N
         if (tile >= tile_count) continue;
-        const int tx = (tile % tile_count_x) * RTX_TILE_SIZE, ty = (tile / tile_count_x) * RTX_TILE_SIZE;
-        const int blk = (int)(l >> 6), ln = (int)(l & 63u);
-        const int px = tx + (blk & 3) * 8 + (ln & 7), py = ty + (blk >> 2) * 8 + (ln >> 3);
+        int px, py; tile_slot_pixel(tile, (int)l, tile_count_x, px, py);
         if (px < width && py < height) fb_packed[(size_t)py * width + px] = gathered[i];
     }
 }

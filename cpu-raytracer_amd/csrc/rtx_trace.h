@@ -46,15 +46,25 @@
 #define RTX_NANFREE_CLOSEST 0    // same for the closest-hit kernel (costs it registers: 119 -> 139 VGPRs, one wave per SIMD less)
 #endif
 
-// Slot -> pixel of a primary ray.  1024 slots per tile, a wave covers an 8x8 pixel block.
-RTX_D bool primary_pixel(const DevScene & sc, const DevQueues & q, uint32_t slot, int & px, int & py) {
-    int tile_k = slot >> 10, l = slot & 1023;
-    int tile = q.first_tile + tile_k * q.tile_stride;
-    int tx = (tile % sc.tile_count_x) * RTX_TILE_SIZE;       // WorkerThread.cpp:57-58
-    int ty = (tile / sc.tile_count_x) * RTX_TILE_SIZE;
-    int blk = l >> 6, ln = l & 63;
+// Tile-major slot order, shared by the primary-ray set-up, k_resolve's tile-major writes, k_unswizzle and the host-side
+// rtx_group_slot_pixels (one definition: host and device cannot disagree).  1024 slots per tile, slot l = 8x8 pixel block l >> 6
+// (row-major blocks of 4 x 4 per tile), pixel l & 63 inside it (row-major): a wave covers one block.
+__host__ __device__ __forceinline__ void tile_slot_pixel(int tile, int l, int tile_count_x, int & px, int & py) {
+    const int tx = (tile % tile_count_x) * RTX_TILE_SIZE;    // WorkerThread.cpp:57-58
+    const int ty = (tile / tile_count_x) * RTX_TILE_SIZE;
+    const int blk = l >> 6, ln = l & 63;
     px = tx + (blk & 3) * 8 + (ln & 7);
     py = ty + (blk >> 2) * 8 + (ln >> 3);
+}
+// GPU group partition: rank r of `world` owns tiles r, r + world, ...; every rank sends tiles_per_rank tiles (padded)
+__host__ __device__ __forceinline__ int group_tiles_per_rank(int tiles_total, int world) { return (tiles_total + world - 1) / world; }
+__host__ __device__ __forceinline__ int group_own_tiles(int tiles_total, int world, int rank) { return rank < tiles_total ? (tiles_total - rank + world - 1) / world : 0; }
+__host__ __device__ __forceinline__ int group_tile_of(int world, int rank, int k) { return rank + k * world; }      // the rank's k-th tile
+
+// Slot -> pixel of a primary ray.
+RTX_D bool primary_pixel(const DevScene & sc, const DevQueues & q, uint32_t slot, int & px, int & py) {
+    const int tile_k = slot >> 10, l = slot & 1023;
+    tile_slot_pixel(q.first_tile + tile_k * q.tile_stride, l, sc.tile_count_x, px, py);
     return px < sc.width && py < sc.height;                  // WorkerThread.cpp:60-61 (clipped tiles)
 }
 

@@ -22,7 +22,7 @@ EXPORTS = ["rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rt
            "rtx_read_framebuffer", "rtx_framebuffer_device_ptrs", "rtx_last_kernel_times", "rtx_enable_kernel_timing",
            "rtx_bind_framebuffer", "rtx_set_stream", "rtx_present", "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample", "rtx_debug_blas_wide",
            "rtx_group_unique_id", "rtx_group_create", "rtx_group_render", "rtx_group_destroy", "rtx_group_attach", "rtx_group_create_local", "rtx_group_render_local",
-           "rtx_debug_group_loopback", "rtx_debug_trace_rays", "rtx_debug_occluded", "rtx_debug_light_plot"]
+           "rtx_group_layout", "rtx_group_slot_pixels", "rtx_debug_group_loopback", "rtx_debug_trace_rays", "rtx_debug_occluded", "rtx_debug_light_plot"]
 
 RTX_RENDER_COUNT_WORK = 1
 RTX_RENDER_SIMPLE_TRACE = 2
@@ -83,6 +83,8 @@ def load_library(path: Optional[str] = None):
     lib.rtx_group_create_local.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
     lib.rtx_group_render_local.argtypes = [C.POINTER(vp), i32, u32]
     lib.rtx_debug_group_loopback.argtypes = [vp, i32, u32]
+    lib.rtx_group_layout.argtypes = [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.rtx_group_slot_pixels.argtypes = [i32, i32, i32, i32, vp, C.c_int64]
     lib.rtx_debug_trace_rays.argtypes = [vp, vp, i32, vp, u32]
     lib.rtx_debug_occluded.argtypes = [vp, vp, i32, vp, u32]
     lib.rtx_debug_light_plot.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32]
@@ -92,6 +94,28 @@ def load_library(path: Optional[str] = None):
             fn.restype = C.c_int
     _lib = lib
     return lib
+
+
+def group_layout(width: int, height: int, world: int, rank: int):
+    """(tiles_total, tiles_per_rank, own_tiles) of rank `rank` of `world` (rtx_group_layout: host function, no GPU needed).  The rank
+    renders rtx_render_tiles(first_tile=rank, tile_stride=world, tile_count=own_tiles)."""
+    lib = load_library()
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = lib.rtx_group_layout(width, height, world, rank, C.byref(a), C.byref(b), C.byref(c))
+    if rc:
+        raise RtxError(rc, "rtx_group_layout")
+    return a.value, b.value, c.value
+
+
+def group_slot_pixels(width: int, height: int, world: int, rank: int) -> np.ndarray:
+    """Raster pixel index of every slot of the rank's tile-major send buffer, -1 = padding (rtx_group_slot_pixels: the kernels' own index maths, on the host)."""
+    lib = load_library()
+    _, per_rank, _ = group_layout(width, height, world, rank)
+    out = np.empty(per_rank * 1024, np.int64)
+    rc = lib.rtx_group_slot_pixels(width, height, world, rank, out.ctypes.data, out.size)
+    if rc:
+        raise RtxError(rc, "rtx_group_slot_pixels")
+    return out
 
 
 class Renderer:

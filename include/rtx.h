@@ -343,6 +343,13 @@ int rtx_group_attach(rtx_ctx * ctx, rtx_group * base, rtx_group ** out_group);
 /* one process driving n GPUs, contexts[i] on its own device = rank i (ncclCommInitAll); render issues all ranks' calls */
 int rtx_group_create_local(rtx_ctx ** contexts, int32_t n, rtx_group ** out_groups);
 int rtx_group_render_local(rtx_group ** groups, int32_t n, uint32_t flags);
+/* The partition and the tile-major slot order as plain host functions (no GPU, no context): the same code the kernels run.
+ * rank `rank` of `world` owns tiles rank, rank + world, ... (numbering of WorkerThread.cpp:57-61: the reference hands those task
+ * numbers to its threads through an atomic counter, :53-65); every rank sends tiles_per_rank tiles of 1024 packed pixels.
+ * rtx_group_slot_pixels: pixel_index[i] = y * width + x of slot i of the rank's send buffer, -1 for padding; rank 0 receives the
+ * send buffers concatenated in rank order.  capacity >= tiles_per_rank * 1024. */
+int rtx_group_layout(int32_t width, int32_t height, int32_t world, int32_t rank, int32_t * tiles_total, int32_t * tiles_per_rank, int32_t * own_tiles);
+int rtx_group_slot_pixels(int32_t width, int32_t height, int32_t world, int32_t rank, int64_t * pixel_index, int64_t capacity);
 
 /* ---- unit-level entry points: one reference function each, evaluated on the device -------------
  * (used by the parity tests; not needed by a renderer)                                          */

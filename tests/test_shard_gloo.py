@@ -1,6 +1,10 @@
-"""N > 1 path on CPU: world-size-2 gloo run of the tile sharding + gather used by bench.py
-(pyrtx/shard.py).  Each rank renders its tile shard with the oracle (test infrastructure standing in
-for the GPU), gathers packed pixels to rank 0, and rank 0 checks the assembled frame."""
+"""N > 1 path on CPU: world-size 2 / 3 gloo runs of the C side's tile partition and tile-major slot order.
+
+What is tested is the index maths of librtx_hip.so itself — rtx_group_layout / rtx_group_slot_pixels are host wrappers around the
+very functions k_resolve's tile-major writes and k_unswizzle use (csrc/rtx_trace.h: group_own_tiles, group_tile_of, tile_slot_pixel).
+Each rank renders the tiles the library says it owns (the oracle stands in for the GPU: test infrastructure), fills its send buffer in
+the library's slot order, one gather to rank 0 as rtx_group_render does it with ncclGather, and rank 0 assembles the frame the way
+k_unswizzle does: slot i of rank r's part goes to the pixel the library names.  The frame must equal the golden frame."""
 import os
 import socket
 import sys
@@ -21,18 +25,25 @@ def _worker(rank, world, port, name, q):
     import torch
     import torch.distributed as dist
     import util, orc
-    from pyrtx import shard
+    from pyrtx import api
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc, g = util.load_golden(name)
-    first, stride, count = shard.shard_args(sc.tile_count, rank, world)
-    out = orc.OracleScene(sc).render(first_tile=first, tile_stride=stride, tile_count=count, threads=2)
-    packed = torch.from_numpy(out["packed"].reshape(-1).view(np.int32).copy())
-    gather = shard.TileGather(sc.width, sc.height, rank, world, "cpu")
-    final = gather(packed)
+    total, per_rank, own = api.group_layout(sc.width, sc.height, world, rank)
+    assert total == sc.tile_count
+    out = orc.OracleScene(sc).render(first_tile=rank, tile_stride=world, tile_count=own, threads=2)
+    packed = out["packed"].reshape(-1).view(np.int32)
+    slots = api.group_slot_pixels(sc.width, sc.height, world, rank)
+    send = torch.from_numpy(np.where(slots >= 0, packed[np.maximum(slots, 0)], 0).astype(np.int32))
+    recv = [torch.zeros(per_rank * 1024, dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, recv, dst=0)
     stats = torch.tensor([out["stats"][k] for k in ("primary", "shadow", "reflection", "refraction")], dtype=torch.int64)
     dist.all_reduce(stats)
     if rank == 0:
-        ok = np.array_equal(final.numpy().view(np.uint32).reshape(sc.height, sc.width), g["packed"])
+        frame = np.zeros(sc.width * sc.height, np.int32)
+        for r in range(world):
+            sl = api.group_slot_pixels(sc.width, sc.height, world, r)
+            frame[sl[sl >= 0]] = recv[r].numpy()[sl >= 0]
+        ok = np.array_equal(frame.view(np.uint32).reshape(sc.height, sc.width), g["packed"])
         q.put((ok, stats.tolist() == g["stats"].tolist()))
     dist.destroy_process_group()
 
@@ -53,11 +64,29 @@ def test_tile_shard_gather_gloo(name, world):
     assert frame_ok and stats_ok
 
 
-def test_tile_partition_covers_every_pixel_once():
-    from pyrtx import shard
-    for (w, h, world) in [(320, 180, 2), (1920, 1080, 8), (301, 173, 3), (32, 32, 4)]:
+def test_c_side_partition_covers_every_pixel_once():
+    from pyrtx import api
+    for (w, h, world) in [(320, 180, 2), (1920, 1080, 8), (301, 173, 3), (32, 32, 4), (64, 32, 5)]:
         seen = np.zeros(w * h, np.int32)
+        tiles = ((w + 31) // 32) * ((h + 31) // 32)
+        owned = 0
         for r in range(world):
-            idx = shard.tile_pixel_indices(w, h, r, world)
+            total, per_rank, own = api.group_layout(w, h, world, r)
+            assert total == tiles and per_rank == (tiles + world - 1) // world and own == len(range(r, tiles, world))
+            owned += own
+            idx = api.group_slot_pixels(w, h, world, r)
+            assert idx.size == per_rank * 1024
+            assert np.all(idx[own * 1024:] == -1)                      # padding tiles carry no pixel
             np.add.at(seen, idx[idx >= 0], 1)
-        assert np.all(seen == 1), (w, h, world)
+        assert owned == tiles and np.all(seen == 1), (w, h, world)
+
+
+def test_c_side_slot_order_is_the_wave_order():
+    """slot l of a tile = 8x8 block l >> 6 (4 blocks per tile row), pixel l & 63 in it: 64 consecutive slots = one wave's packet"""
+    from pyrtx import api
+    idx = api.group_slot_pixels(64, 64, 1, 0).reshape(4, 16, 8, 8)      # tile, block, row, column
+    ys, xs = idx // 64, idx % 64
+    for t in range(4):
+        for b in range(16):
+            assert np.array_equal(xs[t, b], np.tile((t % 2) * 32 + (b % 4) * 8 + np.arange(8), (8, 1)))
+            assert np.array_equal(ys[t, b], np.tile(((t // 2) * 32 + (b // 4) * 8 + np.arange(8))[:, None], (1, 8)))
