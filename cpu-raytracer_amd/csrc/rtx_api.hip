@@ -34,6 +34,34 @@ struct DevBuf {
     void * p = nullptr; size_t cap = 0;
 };
 
+// Tuning knobs (environment, A/B runs and tests): read ONCE per context in rtx_create, validated and clamped there; a value that does not
+// parse or lies outside its range leaves the default in place.  Nothing on the render path calls getenv.
+static long long knob_int(const char * name, long long dflt, long long lo, long long hi) {
+    const char * e = getenv(name);
+    if (!e || !*e) return dflt;
+    char * end = nullptr; const long long v = strtoll(e, &end, 10);
+    if (end == e || *end != 0 || v < lo || v > hi) { fprintf(stderr, "librtx_hip: %s=%s ignored (expected an integer in [%lld, %lld])\n", name, e, lo, hi); return dflt; }
+    return v;
+}
+static double knob_real(const char * name, double dflt, double lo, double hi) {
+    const char * e = getenv(name);
+    if (!e || !*e) return dflt;
+    char * end = nullptr; const double v = strtod(e, &end);
+    if (end == e || *end != 0 || !(v >= lo && v <= hi)) { fprintf(stderr, "librtx_hip: %s=%s ignored (expected a number in [%g, %g])\n", name, e, lo, hi); return dflt; }
+    return v;
+}
+struct Knobs {
+    long long slot_budget;       // RTX_SLOT_BUDGET        ray slots per batch of tiles (plan_batch)
+    long long item_bytes_max;    // RTX_PK_ITEM_BYTES      upper bound of the split walk's item buffer per context
+    int shade_grid;              // RTX_SHADE_GRID         k_shade workgroups per CU
+    int lane_from_level;         // RTX_LANE_FROM_LEVEL    per-lane kernels from this level on (-1: the rule in render_tiles_impl)
+    int lane_from_level_any;     // RTX_LANE_FROM_LEVEL_ANY  the same for shadow rays only (-1: follow the rule)
+    int split_items;             // RTX_PK_SPLIT           split shadow-ray walk: 0 = off, else the smallest item chunk
+    int resolve_block;           // RTX_RESOLVE_BLOCK      k_resolve workgroup size
+    int pk4_order;               // RTX_PK4_ORDER          slot order of the 4-wide records (0: smallest stack need first)
+    bool merge_any, no_wide, fail_item_alloc;
+};
+
 struct KernelTime { const char * name; hipEvent_t a, b; };
 
 struct rtx_ctx {
@@ -53,7 +81,7 @@ struct rtx_ctx {
     std::vector<void *> tex_allocs;
     int material_count = 0, sky_size = 0;
     // host copies for validate_references(): every id a kernel will follow is checked on the host before anything is launched
-    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true; int lane_from_level = -1; bool no_wide = false; int split_items = 0, item_blocks = 0, resolve_block = 256; DevBuf d_pk_items, d_pk_item_count;
+    std::vector<rtx_material> h_materials; std::vector<int> blas_max_local_material, blas_inner_depth, blas_packet_ok; int tlas_inner_depth = -1; std::vector<int> frame_primitive_materials; bool refs_dirty = true; Knobs knobs; int item_blocks = 0, item_cap_alloc = 0; DevBuf d_pk_items, d_pk_item_count;
 
     // per-frame state (rtx_set_frame): ONE device block, filled by one asynchronous copy on the context's stream from a ring of pinned
     // staging buffers — the host never waits for the GPU between frames (cfg5: Scene::update + TLAS rebuild every frame)
@@ -69,7 +97,6 @@ struct rtx_ctx {
     DevBuf d_stats_partial, d_pk_fifo, d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma, d_pk_heads;
     int trace_blocks_closest = 0, trace_blocks_any = 0, trace_blocks_count = 0;
     int pk_blocks_closest = 0, pk_blocks_any = 0;    // persistent grids of the packet kernels (even: waves % 8 == 0, see k_begin_batch)
-    bool merge_any = true;               // one-stream mode: ONE shadow-ray launch for all levels after the last shade (RTX_SERIAL_MERGE_ANY=0: one per level)
 
     rtx_stats stats_acc; rtx_work_counters work_acc; uint32_t err_flags_acc = 0;
     bool stats_pending = false;
@@ -134,7 +161,7 @@ static void convert_nodes_pk(const rtx_bvh_node * nodes, int n, std::vector<floa
 // at this node — then smallest stack need first, which bounds the occupancy by the tree's Strahler-like number.  *stack_need = the bound.
 //   record (128 B, at byte offset 64 * left-child index of j): 4 x { min.x, min.y, max.x, max.y, min.z, max.z, first, leaf count };
 //   first = left-child index of the slot node (inner, count 0) or first triangle (leaf); unused slots hold a point box, which never passes.
-static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, std::vector<float4> & out, int * stack_need) {
+static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, std::vector<float4> & out, int * stack_need, int order_mode) {
     if (n >= (1 << 24) || tri_count >= (1 << 24)) return false;
     auto inside = [&](int c, int p) {
         for (int a = 0; a < 3; a++) if (!(nodes[c].aabb_min[a] >= nodes[p].aabb_min[a] && nodes[c].aabb_max[a] <= nodes[p].aabb_max[a])) return false;
@@ -156,7 +183,7 @@ static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, st
     // visiting order = slot order.  For a shadow ray any hit ends the walk, so the likeliest occluder should come first: largest box first
     // (merged launch 0.652 -> 0.627 ms; by triangle count, density or an RTSAH-style area^2 / cost key: 0.635-0.70).  Where that order would
     // need more packet-stack entries than the cap, the node falls back to the order that minimises the need (smallest need first).
-    int order_mode = 1; if (const char * e = getenv("RTX_PK4_ORDER")) order_mode = atoi(e);      // 0: always smallest need first (A/B runs)
+    // order_mode (RTX_PK4_ORDER) 0: always smallest need first (A/B runs)
     auto area = [&](int i) { const double dx = (double)nodes[i].aabb_max[0] - nodes[i].aabb_min[0], dy = (double)nodes[i].aabb_max[1] - nodes[i].aabb_min[1], dz = (double)nodes[i].aabb_max[2] - nodes[i].aabb_min[2]; const double v = dx * dy + dy * dz + dz * dx; return v == v ? (v < 1e300 ? v : 1e300) : 0.0; };      // a total order even for infinite boxes
     for (size_t k = order.size(); k-- > 0; ) {                      // children before parents
         const int j = order[k], l = nodes[j].left_or_first;
@@ -242,8 +269,22 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     hipMemset(c->d_fb_rgb.p, 0, px * 12);
     hipMemset(c->d_fb_packed.p, 0, px * 4);
 
+    // ---- knobs: parsed once, validated, clamped (see struct Knobs) ----
+    Knobs & K = c->knobs;
+    K.slot_budget = knob_int("RTX_SLOT_BUDGET", SLOT_BUDGET, 1024, 1ll << 31);
+    K.item_bytes_max = knob_int("RTX_PK_ITEM_BYTES", 1ll << 30, 0, 1ll << 36);
+    K.shade_grid = (int)knob_int("RTX_SHADE_GRID", 4, 1, 64);
+    K.lane_from_level = (int)knob_int("RTX_LANE_FROM_LEVEL", -1, 0, 1 << 20);
+    K.lane_from_level_any = (int)knob_int("RTX_LANE_FROM_LEVEL_ANY", -1, 0, 1 << 20);
+    K.split_items = (int)knob_int("RTX_PK_SPLIT", 256, 0, 1 << 16);
+    if (K.split_items > 0) K.split_items = (K.split_items + 63) & ~63;          // chunks are whole units of 64 items
+    K.resolve_block = (int)knob_int("RTX_RESOLVE_BLOCK", 256, 64, 256);
+    if (K.resolve_block != 64 && K.resolve_block != 128 && K.resolve_block != 256) K.resolve_block = 256;
+    K.pk4_order = (int)knob_int("RTX_PK4_ORDER", 1, 0, 1);
+    K.merge_any = knob_int("RTX_SERIAL_MERGE_ANY", 1, 0, 1) != 0;       // one-stream mode: ONE shadow-ray launch for all levels after the last shade (0: one per level)
+    K.no_wide = knob_int("RTX_PK_WIDE", 1, 0, 1) == 0;                  // 0: binary shadow-ray walk for every mesh
+    K.fail_item_alloc = knob_int("RTX_DEBUG_FAIL_ITEM_ALLOC", 0, 0, 1) != 0;      // tests: the item buffer's allocation fails (a size no device has), the fallback kernel must take over
     int bpc = 0;
-    if (const char * e = getenv("RTX_SERIAL_MERGE_ANY")) c->merge_any = atoi(e) != 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<false>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_closest = c->n_cu * (bpc > 0 ? bpc : 2);
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<true>, RTX_TRACE_BLOCK, 0);
@@ -254,9 +295,13 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->pk_blocks_closest = (c->n_cu * (bpc > 0 ? bpc : 4) + 1) & ~1;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_packet<true, false>, RTX_PK_BLOCK, 0);
     c->pk_blocks_any = (c->n_cu * (bpc > 0 ? bpc : 4) + 1) & ~1;
-    if (const char * e = getenv("RTX_PK_GRID_SCALE")) { const double f = atof(e); if (f > 0.0) { c->pk_blocks_closest = ((int)(c->pk_blocks_closest * f) + 1) & ~1; c->pk_blocks_any = ((int)(c->pk_blocks_any * f) + 1) & ~1; } }
-    if (const char * e = getenv("RTX_PK_GRID_ANY")) { const double f = atof(e); if (f > 0.0) c->pk_blocks_any = ((int)(c->n_cu * f) + 1) & ~1; }          // blocks per CU (A/B runs)
-    if (const char * e = getenv("RTX_PK_GRID_CLOSEST")) { const double f = atof(e); if (f > 0.0) c->pk_blocks_closest = ((int)(c->n_cu * f) + 1) & ~1; }
+    {   // persistent-grid sizes of the packet kernels (A/B runs): a scale on the occupancy-derived size, or blocks per CU
+        const double f = knob_real("RTX_PK_GRID_SCALE", 1.0, 0.05, 16.0);
+        if (f != 1.0) { c->pk_blocks_closest = ((int)(c->pk_blocks_closest * f) + 1) & ~1; c->pk_blocks_any = ((int)(c->pk_blocks_any * f) + 1) & ~1; }
+        const double fa = knob_real("RTX_PK_GRID_ANY", 0.0, 0.05, 64.0), fc = knob_real("RTX_PK_GRID_CLOSEST", 0.0, 0.05, 64.0);
+        if (fa > 0.0) c->pk_blocks_any = ((int)(c->n_cu * fa) + 1) & ~1;
+        if (fc > 0.0) c->pk_blocks_closest = ((int)(c->n_cu * fc) + 1) & ~1;
+    }
     {   // the packet queues hand out packets k * 8 + head after a static first round of one packet per wave: whole rounds only, so waves % 8 == 0
         const int g = RTX_PK_CLASSES * RTX_WAVE / RTX_PK_BLOCK > 1 ? RTX_PK_CLASSES * RTX_WAVE / RTX_PK_BLOCK : 1;
         c->pk_blocks_any = (c->pk_blocks_any + g - 1) / g * g; c->pk_blocks_closest = (c->pk_blocks_closest + g - 1) / g * g;
@@ -266,20 +311,17 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     if ((long long)c->trace_blocks_count * RTX_TRACE_BLOCK > max_threads) max_threads = (long long)c->trace_blocks_count * RTX_TRACE_BLOCK;
     if ((long long)c->pk_blocks_any * RTX_PK_BLOCK > max_threads) max_threads = (long long)c->pk_blocks_any * RTX_PK_BLOCK;       // the packet kernels' per-lane phases spill there too
     if ((long long)c->pk_blocks_closest * RTX_PK_BLOCK > max_threads) max_threads = (long long)c->pk_blocks_closest * RTX_PK_BLOCK;
-    c->q.pk_defer_t0 = 8; if (const char * e = getenv("RTX_PK_DEFER")) c->q.pk_defer_t0 = atoi(e);
-    c->q.pk_defer_leaf = c->q.pk_defer_t0 / 2; if (const char * e = getenv("RTX_PK_DEFER_LEAF")) c->q.pk_defer_leaf = atoi(e);
-    c->q.pk_defer_t0_closest = 64; if (const char * e = getenv("RTX_PK_DEFER_CLOSEST")) c->q.pk_defer_t0_closest = atoi(e);
-    c->q.pk_order = 1; if (const char * e = getenv("RTX_PK_ORDER")) c->q.pk_order = atoi(e);
-    if (const char * e = getenv("RTX_RESOLVE_BLOCK")) { const int b = atoi(e); if (b == 64 || b == 128 || b == 256) c->resolve_block = b; }      // k_resolve workgroup size (A/B runs)
-    if (const char * e = getenv("RTX_PK_WIDE")) c->no_wide = atoi(e) == 0;
-    if (const char * e = getenv("RTX_LANE_FROM_LEVEL")) c->lane_from_level = atoi(e);      // per-lane kernels from this level on (default: 2 for multi-instance scenes, never otherwise)      // RTX_PK_WIDE=0: binary shadow-ray walk for every mesh
-    c->q.pk_defer_grow = 3; if (const char * e = getenv("RTX_PK_GROW")) c->q.pk_defer_grow = atoi(e);
+    // deferral thresholds of the hybrid walks are lane counts (0 .. 64), the growth a shift count: anything else would reach the asm walkers as garbage
+    c->q.pk_defer_t0 = (int)knob_int("RTX_PK_DEFER", 8, 0, 64);
+    c->q.pk_defer_leaf = (int)knob_int("RTX_PK_DEFER_LEAF", c->q.pk_defer_t0 / 2, 0, 64);
+    c->q.pk_defer_t0_closest = (int)knob_int("RTX_PK_DEFER_CLOSEST", 64, 0, 64);
+    c->q.pk_order = (int)knob_int("RTX_PK_ORDER", 1, 0, 1);
+    c->q.pk_defer_grow = (int)knob_int("RTX_PK_GROW", 3, 0, 31);
     c->q.spill_threads = (int)max_threads;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast
     if (!rc) rc = ensure(c, c->d_pk_fifo, (size_t)c->q.spill_threads * RTX_PK_FIFO * 4);
     { int ib = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&ib, k_items, RTX_ITEM_BLOCK, 0); c->item_blocks = c->n_cu * (ib > 0 ? ib : 4);
-      if (const char * e = getenv("RTX_ITEM_GRID")) { const double f = atof(e); if (f > 0.0) c->item_blocks = (int)(c->n_cu * f); } }
-    c->split_items = 256; if (const char * e = getenv("RTX_PK_SPLIT")) c->split_items = atoi(e);       // split shadow-ray walk: 0 = off, else the smallest item chunk (sized per batch, see render_tiles_impl)
+      const double f = knob_real("RTX_ITEM_GRID", 0.0, 0.05, 64.0); if (f > 0.0) c->item_blocks = (int)(c->n_cu * f) > 0 ? (int)(c->n_cu * f) : 1; }
     c->q.pk_items = nullptr; c->q.pk_item_count = nullptr; c->q.pk_item_cap = 0;      // sized per render call (render_tiles_impl)
     if (rc) { rtx_destroy(c); return rc; }
     *out_ctx = c;
@@ -351,7 +393,7 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
     }
     std::vector<float4> ndp; convert_nodes_pk(nodes, node_count, ndp);
     std::vector<float4> nd4; int need4 = 0;
-    const bool wide = !c->no_wide && build_nodes_pk4(nodes, node_count, triangle_count, nd4, &need4) && need4 <= RTX_PK4_MAX_NEED;
+    const bool wide = !c->knobs.no_wide && build_nodes_pk4(nodes, node_count, triangle_count, nd4, &need4, c->knobs.pk4_order) && need4 <= RTX_PK4_MAX_NEED;
     void * dn = nullptr, * dt = nullptr, * dc = nullptr, * dnp = nullptr, * dn4 = nullptr;
     if (wide) { HIP_OK(c, hipMalloc(&dn4, nd4.size() * 16)); c->blas_allocs[blas_id].push_back(dn4); HIP_OK(c, hipMemcpy(dn4, nd4.data(), nd4.size() * 16, hipMemcpyHostToDevice)); }
     HIP_OK(c, hipMalloc(&dn, nd.size() * 16)); c->blas_allocs[blas_id].push_back(dn);
@@ -516,7 +558,8 @@ static int validate_references(rtx_ctx * c) {
     // BVH_TRAVERSAL_STACK_SIZE (Config.h:25).  The reference's per-BVH stack holds one pending sibling per ancestor entered through its near
     // child plus the two children pushed while a node is expanded (BottomLevelBVH.cpp:381-387, TopLevelBVH.cpp:76-82) and is not checked:
     // a tree with an inner node at depth d overflows a stack of fewer than d + 2 entries for some ray.  Such a tree is refused here,
-    // for every ray alike; the kernels' own stacks (64 entries) can then never overflow.
+    // for every ray alike.  The per-lane kernels' stacks (64 entries per BVH) can then never overflow; the packet kernels share one 64-entry
+    // stack between TLAS and BLAS, and render_tiles_impl hands scenes that could exceed it to the per-lane kernels.
     for (size_t b = 0; b < c->h_blas.size(); b++)
         if (c->h_blas[b].nodes && b < c->blas_inner_depth.size() && c->blas_inner_depth[b] + 2 > c->cfg.stack_size) {
             c->err = "BVH deeper than rtx_config.stack_size allows (BVH_TRAVERSAL_STACK_SIZE, Config.h:25): an inner node at depth " + std::to_string(c->blas_inner_depth[b]) + " needs " + std::to_string(c->blas_inner_depth[b] + 2) + " stack entries";
@@ -536,8 +579,7 @@ static int plan_batch(rtx_ctx * c, int tiles, int & out_tiles) {
     // worst case: every hit spawns two children -> level d holds P * 2^d rays
     const int levels = c->cfg.bounces + 1;
     const long long per_tile = 1024ll * ((1ll << levels) - 1);
-    long long budget = SLOT_BUDGET;
-    if (const char * e = getenv("RTX_SLOT_BUDGET")) { long long v = atoll(e); if (v > 0) budget = v; }   // tests force multi-batch frames with a small budget
+    const long long budget = c->knobs.slot_budget;          // RTX_SLOT_BUDGET: tests force multi-batch frames with a small budget
     long long t = budget / per_tile;
     if (t < 1) t = 1;
     out_tiles = (int)(t < tiles ? t : tiles);
@@ -630,7 +672,25 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
     const bool cull = (flags & RTX_RENDER_CULL_DEAD_SHADOW_RAYS) != 0 && !simple && !count_work;
     bool lane = (flags & RTX_RENDER_LANE_TRACE) != 0;
     for (size_t b = 0; b < c->blas_packet_ok.size(); b++) if (c->h_blas[b].nodes && !c->blas_packet_ok[b]) lane = true;      // limits of the packet kernels' packed entries
-    const bool pk_closest = (flags & RTX_RENDER_PACKET_CLOSEST) != 0;      // closest-hit packets walk shared subtrees together (default: lanes turn private at once)
+    bool pk_closest = (flags & RTX_RENDER_PACKET_CLOSEST) != 0;            // closest-hit packets walk shared subtrees together (default: lanes turn private at once)
+    {   // The packet kernels keep ONE 64-entry stack per wave (RTX_PK_STACK) for the TLAS part and the BLAS part of a walk together, where the
+        // reference has a stack per BVH (BVH_TRAVERSAL_STACK_SIZE each).  Both depths are known here, so the choice is made on the host
+        // and pk_push's overflow path is never taken:  TLAS part = one pending far sibling per level + the iterator entry of the leaf being
+        // visited (closest-hit rays: + one parked sign-split entry per level); BLAS part = the 4-wide records' bound (pk4_need), or one far
+        // sibling per level of the binary walk; the shared closest-hit walk parks sign-split entries there too.  Scenes beyond the bound
+        // (e.g. a chain-shaped TLAS of 60 instances) are traced by the per-lane kernels, whose stacks are per BVH like the reference's.
+        const int dt = c->tlas_inner_depth < 0 ? 0 : c->tlas_inner_depth + 1;
+        int blas_any = 0, blas_shared = 0;
+        for (size_t b = 0; b < c->h_blas.size(); b++) {
+            if (!c->h_blas[b].nodes) continue;
+            const int depth = b < c->blas_inner_depth.size() ? c->blas_inner_depth[b] + 2 : 2;
+            const int any = c->h_blas[b].pk4_nodes ? c->h_blas[b].pk4_need : depth;
+            if (any > blas_any) blas_any = any;
+            if (2 * depth > blas_shared) blas_shared = 2 * depth;
+        }
+        if (dt + 1 + blas_any > RTX_PK_STACK || 2 * dt + 1 > RTX_PK_STACK) lane = true;
+        if (2 * dt + 1 + blas_shared > RTX_PK_STACK) pk_closest = false;
+    }
     const bool pstat = (flags & RTX_RENDER_PACKET_STATS) != 0 && !simple && !count_work && !lane;
     c->serial = (flags & RTX_RENDER_SERIAL) != 0;
 
@@ -643,10 +703,40 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
     if (rc) return rc;
     const int levels = c->cfg.bounces + 1;
     const int stream_blocks = c->n_cu * 8;          // k_resolve (256 threads)
-    int shade_blocks = c->n_cu * 4;                 // k_shade (RTX_SHADE_BLOCK = 256 threads, 3 resident blocks per CU at 168 VGPRs)
-    if (const char * e = getenv("RTX_SHADE_GRID")) shade_blocks = c->n_cu * atoi(e);
+    const int shade_blocks = c->n_cu * c->knobs.shade_grid;      // k_shade (RTX_SHADE_BLOCK = 256 threads, 3 resident blocks per CU at 168 VGPRs)
     rc = ensure(c, c->d_stats_partial, (size_t)(RTX_MAX_LEVELS + 1) * shade_blocks * 4 * sizeof(uint32_t));
     if (rc) return rc;
+
+    // Item chunks of the split shadow-ray walk (rtx_packet.h, k_items): one chunk per wave of the packet launch, sized ONCE per call for its
+    // largest batch — ≈0.3 items per shadow ray in the cfg3 frame, the fullest chunk 3x the average, so 3.5x the expected average, in
+    // whole units of 64 items.  The buffer only ever grows, never beyond knobs.item_bytes_max (1 GiB; a chunk that fills up merely makes the
+    // packet keep its nodes, which the kernel supports), and only here, before anything of this call is queued.  If the allocation
+    // fails the pending HIP error is cleared and the call continues with the non-split kernel: a correctly queued frame must not
+    // report RTX_ERR_HIP.  The split walk needs 4-wide records for every mesh.
+    c->q.pk_items = nullptr; c->q.pk_item_count = nullptr; c->q.pk_item_cap = 0;
+    if (c->knobs.split_items > 0 && c->scene.light_count > 0) {
+        bool all_wide = true;
+        for (size_t b = 0; b < c->h_blas.size(); b++) if (c->h_blas[b].nodes && !c->h_blas[b].pk4_nodes) all_wide = false;
+        if (all_wide) {
+            const size_t chunks = (size_t)c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE);
+            const double expect = 0.45 * 1024.0 * (double)batch_tiles * c->scene.light_count / (double)chunks;
+            long long cap = c->knobs.split_items;
+            if (cap < (long long)(3.5 * expect)) cap = ((long long)(3.5 * expect) + 63) & ~63ll;
+            const long long cap_max = (c->knobs.item_bytes_max / (long long)(chunks * 48)) & ~63ll;
+            if (cap > cap_max) cap = cap_max;
+            if (cap > (1 << 16)) cap = 1 << 16;
+            if (cap >= 64) {
+                if (cap <= c->item_cap_alloc && c->d_pk_items.p && !c->knobs.fail_item_alloc) cap = c->item_cap_alloc;      // the buffer is there already
+                else {
+                    c->item_cap_alloc = 0;
+                    const size_t bytes = c->knobs.fail_item_alloc ? ((size_t)1 << 46) : chunks * (size_t)cap * 48;
+                    if (ensure(c, c->d_pk_items, bytes) == 0 && ensure(c, c->d_pk_item_count, chunks * 4) == 0) c->item_cap_alloc = (int)cap;
+                    else { (void)hipGetLastError(); c->err.clear(); cap = 0; }       // fall back to the in-kernel per-lane phase
+                }
+                if (cap >= 64) { c->q.pk_items = (uint4 *)c->d_pk_items.p; c->q.pk_item_count = (uint32_t *)c->d_pk_item_count.p; c->q.pk_item_cap = (int)cap; }
+            }
+        }
+    }
 
     for (int done = 0; done < tile_count; done += batch_tiles) {
         const int n = (tile_count - done) < batch_tiles ? (tile_count - done) : batch_tiles;
@@ -667,7 +757,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         // three of the per-launch tails (a persistent trace launch has a ~0.17 ms floor set by its slowest rays).
         const bool overlap = !count_work && !simple && sc.light_count > 0 && !c->serial;
         if (overlap && !c->any_stream) HIP_OK(c, hipStreamCreateWithFlags(&c->any_stream, hipStreamNonBlocking));
-        const bool merged = !overlap && !count_work && !simple && c->merge_any;
+        const bool merged = !overlap && !count_work && !simple && c->knobs.merge_any;
         if (sc.heatmap) {
             // BVH_VISUALIZE_HEATMAP: bounce() returns right after the primary ray's trace (Raytracer.cpp:97-102), so a frame is one
             // closest-hit pass in reference pop order (the plain kernel counts the steps) and one colouring pass
@@ -684,13 +774,13 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         // 0.19 / 0.14 ms) while the packet kernels win everywhere else (tools/perlevel3.py).  Both produce the same bits.
         // With hundreds of instances the closest-hit reflection rays of level 1 already prefer the per-lane kernel (tools/many_instances.py:
         // 144 instances 0.52 vs 0.40 ms, 576 instances 0.70 vs 0.39 ms), the shadow rays of level 1 do not (0.48 vs 0.8 ms).
-        int lane_from = c->lane_from_level >= 0 ? c->lane_from_level : (sc.instance_count > 1 ? 2 : RTX_MAX_LEVELS + 1);
-        const int lane_from_closest = c->lane_from_level >= 0 ? c->lane_from_level : (sc.instance_count > 64 ? 1 : lane_from);
+        int lane_from = c->knobs.lane_from_level >= 0 ? c->knobs.lane_from_level : (sc.instance_count > 1 ? 2 : RTX_MAX_LEVELS + 1);
+        const int lane_from_closest = c->knobs.lane_from_level >= 0 ? c->knobs.lane_from_level : (sc.instance_count > 64 ? 1 : lane_from);
         // With the split walk a shadow-ray packet that enters an instance with few lanes hands the whole visit over as items, and ONE packet
         // launch for all levels beats a packet launch + a per-lane launch at every instance count measured (tools/any_rule.sh: 16 / 144 / 576
         // instances 1.54 / 2.24 / 3.01 vs 1.66 / 2.41 / 3.05 ms per frame, cfg5 2.32 vs 2.42): shadow rays then stay with the packets
-        if (c->lane_from_level < 0 && c->split_items > 0 && sc.light_count > 0) { bool all_wide = true; for (size_t b = 0; b < c->h_blas.size(); b++) if (c->h_blas[b].nodes && !c->h_blas[b].pk4_nodes) all_wide = false; if (all_wide) lane_from = RTX_MAX_LEVELS + 1; }
-        if (const char * e = getenv("RTX_LANE_FROM_LEVEL_ANY")) lane_from = atoi(e);        // shadow rays only (A/B runs)
+        if (c->knobs.lane_from_level < 0 && c->knobs.split_items > 0 && sc.light_count > 0) { bool all_wide = true; for (size_t b = 0; b < c->h_blas.size(); b++) if (c->h_blas[b].nodes && !c->h_blas[b].pk4_nodes) all_wide = false; if (all_wide) lane_from = RTX_MAX_LEVELS + 1; }
+        if (c->knobs.lane_from_level_any >= 0) lane_from = c->knobs.lane_from_level_any;      // shadow rays only (A/B runs)
         auto launch_closest = [&](int level) {
             launch_timed(c, "k_trace_closest", c->stream, [&] {
                 if (count_work)     hipLaunchKernelGGL((k_trace<false, true>),   dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
@@ -700,20 +790,8 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
                 else                hipLaunchKernelGGL((k_packet<false, false>), dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
             });
         };
-        // split shadow-ray walk (RTX_PK_SPLIT): the items the packet launch emitted, one per lane
-        // item chunks of the split shadow-ray walk: one per wave of the packet launch, sized from the batch (≈0.3 items per shadow ray in the
-        // cfg3 frame, the fullest chunk 3x the average; a full chunk only makes the packet keep its nodes): 4x the expected average, a power of two
-        if (c->split_items > 0 && sc.light_count > 0) {
-            const size_t chunks = (size_t)c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE);
-            const double expect = 0.45 * (double)q.primary_slots * sc.light_count / (double)chunks;
-            int cap = c->split_items; while (cap < 4.0 * expect && cap < (1 << 16)) cap *= 2;
-            if (ensure(c, c->d_pk_items, chunks * (size_t)cap * 48) == 0 && ensure(c, c->d_pk_item_count, chunks * 4) == 0) {
-                q.pk_items = (uint4 *)c->d_pk_items.p; q.pk_item_count = (uint32_t *)c->d_pk_item_count.p; q.pk_item_cap = cap;
-            }
-        }
-        bool split = q.pk_items != nullptr;                   // needs 4-wide records for every mesh
-        for (size_t b = 0; b < c->h_blas.size(); b++) if (c->h_blas[b].nodes && !c->h_blas[b].pk4_nodes) split = false;
-        if (!split) { q.pk_items = nullptr; q.pk_item_count = nullptr; q.pk_item_cap = 0; }
+        // split shadow-ray walk (RTX_PK_SPLIT): q.pk_items / q.pk_item_cap were sized for this call's largest batch before the loop
+        const bool split = q.pk_items != nullptr;
         auto launch_items = [&](hipStream_t st, int lo) {
             if (!split) return;
             launch_timed(c, "k_trace_items", st, [&] { hipLaunchKernelGGL(k_items, dim3(c->item_blocks), dim3(RTX_ITEM_BLOCK), 0, st, sc, q, c->pk_blocks_any * (RTX_PK_BLOCK / RTX_WAVE), lo); });
@@ -762,7 +840,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         }
         if (overlap) { hipEventRecord(c->ev_any_done, c->any_stream); hipStreamWaitEvent(c->stream, c->ev_any_done, 0); }
         for (int level = levels - 1; level >= 0; level--)
-            launch_timed(c, "k_resolve", c->stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(stream_blocks * (256 / c->resolve_block)), dim3(c->resolve_block), 0, c->stream, sc, q, level); });
+            launch_timed(c, "k_resolve", c->stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(stream_blocks * (256 / c->knobs.resolve_block)), dim3(c->knobs.resolve_block), 0, c->stream, sc, q, level); });
     }
     HIP_OK(c, hipGetLastError());
     c->stats_pending = true;

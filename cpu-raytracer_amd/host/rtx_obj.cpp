@@ -3,10 +3,10 @@
 // Produces exactly the triangle soup the reference's OBJLoader::load_obj builds (OBJLoader.cpp:70-187): faces in file
 // order, polygons triangulated, texture v flipped (OBJLoader.cpp:139-141), per-face material id with -1 mapped to 0
 // (:172-173), materials as OBJLoader.cpp:8-41 fills them (Kd / Ks / Kt|Tf / Ni / map_Kd, magenta stand-in when the MTL
-// has no material).  The reference delegates parsing to the vendored tinyobjloader 2.0 header; what is restated here (own
-// code) is that library's observable behaviour for the constructs these assets use:
-//   * decimal number parsing (integer part by repeated x10, fraction by table / pow(10,-k), exponent via
-//     ldexp(m * 5^e, e)), then a cast to float — it can differ from strtod in the last bit, so it is reproduced;
+// has no material).  The reference delegates parsing to the vendored tinyobjloader 2.0 header (MIT); what is restated here
+// is that library's observable behaviour for the constructs these assets use:
+//   * decimal number parsing — parse_double / parse_real are DERIVED from tinyobjloader's tryParseDouble / parseReal (attribution
+//     and licence notice at the function): it can differ from strtod in the last bit, so its exact operation sequence is kept;
 //   * index fix-up (1-based, negative = relative), "v", "v/vt", "v//vn", "v/vt/vn";
 //   * polygon triangulation by ear clipping in the dominant-axis projection (triangles pass through untouched);
 //   * material defaults (all colours 0, Ni 1).
@@ -25,6 +25,24 @@ namespace {
 
 bool is_digit(char c) { return c >= '0' && c <= '9'; }
 
+// ---- decimal number parsing: derived from tinyobjloader ---------------------------------------------------------------------------
+// parse_double / parse_real below follow tinyobjloader 2.0's tryParseDouble / parseReal (the copy the reference vendors:
+// include/tiny_obj_loader/tiny_obj_loader.h:805-940) operation for operation — digit accumulation by repeated x10, the eight-entry
+// fraction table, pow(10, -k) beyond it, ldexp(mantissa * pow(5, e), e) for exponents, then a cast to float.  That sequence is NOT
+// strtod (it can differ in the last bit of the float), and bit-identical vertices need exactly it, so this function is a compacted
+// restatement of that third-party code rather than independent work.  tinyobjloader is MIT-licensed:
+//
+//   The MIT License (MIT)
+//   Copyright (c) 2012-2018 Syoyo Fujita and many contributors.
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated documentation files
+//   (the "Software"), to deal in the Software without restriction, including without limitation the rights to use, copy, modify, merge,
+//   publish, distribute, sublicense, and/or sell copies of the Software, and to permit persons to whom the Software is furnished to do
+//   so, subject to the following conditions:
+//   The above copyright notice and this permission notice shall be included in all copies or substantial portions of the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE WARRANTIES OF
+//   MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE
+//   FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN
+//   CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
 bool parse_double(const char * s, const char * end, double * out) {
     if (s >= end) return false;
     double mantissa = 0.0; int exponent = 0; char sign = '+', esign = '+';

@@ -62,8 +62,10 @@ def run_ref(variant, script_path, name):
     if not os.path.exists(exe):
         parts = variant.split("_")
         s, m, b, t = [x[1:] for x in parts[:4]]
+        aniso = [x[1:] + ".0f" for x in parts[4:] if x[0] == "a" and x[1:].isdigit()]
         subprocess.check_call(["make", "-C", HERE, "variant", f"SCENE={s}", f"MIP={m}", f"BOUNCES={b}", f"TEXMODE={t}",
-                               "ACCEL=" + ("0" if "bvh" in parts[4:] else "1"), "HEAT=" + ("true" if "heat" in parts[4:] else "false")])
+                               "ACCEL=" + ("0" if "bvh" in parts[4:] else "1"), "HEAT=" + ("true" if "heat" in parts[4:] else "false"),
+                               "TRAVERSAL=" + ("0" if "naive" in parts[4:] else "1"), "ANISO=" + (aniso[0] if aniso else "8.0f")])
     out = os.path.join(WORK, "out_" + name)
     shutil.rmtree(out, ignore_errors=True)
     subprocess.check_call([exe, script_path, out], cwd=WORK, stdout=subprocess.DEVNULL)
@@ -126,6 +128,17 @@ def main():
 
     tp = ["texprobe ./Data/Floor.png 2048 12345", "texprobe ./Data/LEGOSHLD.tga 2048 777"]
     mat_extra = ["size 320 180", "matset mesh:0:0 texture ./Data/LEGOSHLD.tga"] + tp
+
+    def knob_goldens():
+        # the remaining Config.h values, each as its own build of the reference on the `materials` scene (scene file shared with the
+        # other materials goldens; tests/util.py applies the config override): BVH_TRAVERSE_TREE_NAIVE (Config.h:27),
+        # TEXTURE_SAMPLE_MODE_NEAREST (:38), MAX_ANISOTROPY 2 (:55), NUMBER_OF_BOUNCES 1 and 5 (:12)
+        for tag, variant, more in (("naive", "s0_m1_b3_t2_naive", []), ("nearest", "s0_m1_b3_t0", []), ("aniso2", "s0_m1_b3_t2_a2", tp),
+                                   ("b1", "s0_m1_b1_t2", ["bounces 1"]), ("b5", "s0_m1_b5_t2", ["bounces 5"])):
+            golden("materials", "materials", variant, extra=mat_extra[:2] + more, tag=tag, keep_scene=False)
+    if "--knobs-only" in sys.argv:
+        knob_goldens()
+        return
     # BVH_VISUALIZE_HEATMAP builds (Config.h:23, Raytracer.cpp:97-102): same scenes, pixels = BLAS traversal steps
     golden("monkey_small", "monkey_small", "s0_m1_b3_t2_heat", keep_scene=False, tag="heat")
     golden("materials", "materials", "s0_m1_b3_t2_heat", extra=mat_extra[:2], keep_scene=False, tag="heat")
@@ -152,6 +165,7 @@ def main():
         n0 = int(x.desc["width"][0]) * int(x.desc["height"][0])
         assert np.array_equal(x.texels[:n0], y.texels[:n0]) and int(y.desc["mipmapped"][0]) == 0
 
+    knob_goldens()
     golden("dynamic", "dynamic", "s1_m2_b3_t2", extra=["size 320 180"])
     golden("tori16", "tori16", "s1_m2_b3_t2", extra=["size 320 180"])
     golden("tori16_f1", "tori16", "s1_m2_b3_t2", extra=["size 320 180", "frames 1 0.0166666667"])

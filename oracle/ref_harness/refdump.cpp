@@ -42,6 +42,9 @@
 #undef private
 
 #include "../../include/rtx.h"
+#ifdef REFBIND
+#include "WorkerThread.h"      // the four WorkerThreads entry points; implemented by GpuBackend.cpp in this build (refbind_* binaries)
+#endif
 
 // ---- headless Window (Window.cpp is SDL/GL and is not compiled) -------------------------------
 Window::Window(int width, int height, const char * title) :
@@ -107,7 +110,10 @@ int main(int argc, char ** argv) {
 	if (argc < 3) { fprintf(stderr, "usage: refdump <script> <outdir> [--threads N]\n  (cwd must contain ./Data as the reference expects, Util.h:6)\n"); return 2; }
 	std::string script = argv[1], outdir = argv[2];
 	int mt_threads = 0, mt_frames = 3; bool timing_only = false;           // --threads N [--frames K] [--timing-only]: the reference's worker pool, timed
+	int binding_frames = 0; float binding_delta = 1.0f / 60.0f;            // --gpu-binding N [--binding-delta s]: refbind_* builds only, see below
 	for (int a = 3; a < argc; a++) {
+		if (!strcmp(argv[a], "--gpu-binding") && a + 1 < argc) { binding_frames = atoi(argv[++a]); continue; }
+		if (!strcmp(argv[a], "--binding-delta") && a + 1 < argc) { binding_delta = (float)atof(argv[++a]); continue; }
 		if (!strcmp(argv[a], "--threads") && a + 1 < argc) mt_threads = atoi(argv[++a]);
 		else if (!strcmp(argv[a], "--frames") && a + 1 < argc) mt_frames = atoi(argv[++a]);
 		else if (!strcmp(argv[a], "--timing-only")) timing_only = true;
@@ -242,6 +248,56 @@ int main(int argc, char ** argv) {
 
 	Raytracer raytracer;
 	raytracer.scene = &scene;
+
+	// ---- the drop-in binding, executed (refbind_* builds): Main.cpp:51-57's loop with GpuBackend.cpp standing where WorkerThread.cpp
+	//      stood, next to the reference's own render_tile loop on the SAME Scene / Window objects.  Per frame: scene.update(delta);
+	//      reference tiles -> Window::frame_buffer (kept aside); WorkerThreads::wake_up_worker_threads + wait_on_worker_threads ->
+	//      Window::frame_buffer again, through rtx_set_frame / rtx_render_tiles / rtx_read_framebuffer; the two must be equal in every
+	//      pixel, and sum_performance_stats() must return the reference's ray counts.
+	if (binding_frames > 0) {
+#ifdef REFBIND
+		if (bounces != NUMBER_OF_BOUNCES) { fprintf(stderr, "--gpu-binding: the script's bounces must equal this build's NUMBER_OF_BOUNCES (%d)\n", NUMBER_OF_BOUNCES); return 2; }
+		const int tiles = window.tile_count_x * window.tile_count_y;
+		std::vector<unsigned> ref_fb((size_t)W * H);
+		std::vector<long> mismatches; std::vector<int> stats_ok; bool identical = true;
+		PerformanceStats last_ref = { 0, 0, 0, 0 }, last_gpu = { 0, 0, 0, 0 };
+		for (int f = 0; f < binding_frames; f++) {
+			scene.update(f == 0 ? 0.0f : binding_delta);                                       // Main.cpp:54
+			PerformanceStats sr = { 0, 0, 0, 0 };
+			for (int task = tiles - 1; task >= 0; task--) {                                  // WorkerThread.cpp:53-65, one thread
+				int x = (task % window.tile_count_x) * window.tile_width, y = (task / window.tile_count_x) * window.tile_height;
+				int tw = x + window.tile_width  < window.width  ? window.tile_width  : window.width  - x;
+				int th = y + window.tile_height < window.height ? window.tile_height : window.height - y;
+				raytracer.render_tile(window, x, y, tw, th, sr);
+			}
+			memcpy(ref_fb.data(), window.frame_buffer, ref_fb.size() * sizeof(unsigned));
+			memset(window.frame_buffer, 0xCD, ref_fb.size() * sizeof(unsigned));
+			if (f == 0) WorkerThreads::init(raytracer, window);                                // Main.cpp:46
+			WorkerThreads::wake_up_worker_threads(tiles);                                      // Main.cpp:56
+			WorkerThreads::wait_on_worker_threads();                                           // Main.cpp:57
+			const PerformanceStats sg = WorkerThreads::sum_performance_stats();
+			long bad = 0;
+			for (size_t p = 0; p < ref_fb.size(); p++) if (ref_fb[p] != window.frame_buffer[p]) bad++;
+			const int sok = sr.num_primary_rays == sg.num_primary_rays && sr.num_shadow_rays == sg.num_shadow_rays &&
+			                sr.num_reflection_rays == sg.num_reflection_rays && sr.num_refraction_rays == sg.num_refraction_rays;
+			mismatches.push_back(bad); stats_ok.push_back(sok); identical = identical && bad == 0 && sok;
+			last_ref = sr; last_gpu = sg;
+		}
+		FILE * jf = fopen((outdir + "/binding.json").c_str(), "w");
+		fprintf(jf, "{\"frames\": %d, \"width\": %d, \"height\": %d, \"identical\": %s, \"mismatched_pixels\": [", binding_frames, W, H, identical ? "true" : "false");
+		for (size_t i = 0; i < mismatches.size(); i++) fprintf(jf, "%s%ld", i ? ", " : "", mismatches[i]);
+		fprintf(jf, "], \"stats_equal\": [");
+		for (size_t i = 0; i < stats_ok.size(); i++) fprintf(jf, "%s%s", i ? ", " : "", stats_ok[i] ? "true" : "false");
+		fprintf(jf, "],\n \"reference_rays\": [%lld, %lld, %lld, %lld], \"binding_rays\": [%lld, %lld, %lld, %lld], \"instances\": %d, \"simd_lane_size\": %d}\n",
+		        (long long)last_ref.num_primary_rays, (long long)last_ref.num_shadow_rays, (long long)last_ref.num_reflection_rays, (long long)last_ref.num_refraction_rays,
+		        (long long)last_gpu.num_primary_rays, (long long)last_gpu.num_shadow_rays, (long long)last_gpu.num_reflection_rays, (long long)last_gpu.num_refraction_rays,
+		        scene.top_level_bvh.primitive_count, SIMD_LANE_SIZE);
+		fclose(jf);
+		return identical ? 0 : 4;
+#else
+		fprintf(stderr, "--gpu-binding needs a refbind_* build (make -C oracle/ref_harness refbind)\n"); return 2;
+#endif
+	}
 
 	// ---- pass 1: the reference's own tile loop (WorkerThread.cpp:53-65, single thread) ------------
 	PerformanceStats stats_tiles = { 0, 0, 0, 0 };

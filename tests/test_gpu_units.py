@@ -17,7 +17,7 @@ def api():
     return a
 
 
-@pytest.mark.parametrize("name", ["materials_aniso", "materials_trilinear", "materials_ewa", "materials_bilinear"])
+@pytest.mark.parametrize("name", ["materials_aniso", "materials_trilinear", "materials_ewa", "materials_bilinear", "materials_aniso2"])
 def test_texture_sample_matches_reference_probes(api, name):
     """Texture::sample (Texture.h:33-49) at 2 x 2048 seeded (s,t,derivative) inputs recorded from the REAL reference.
     Bilinear / trilinear / anisotropic / EWA.  log2f (mip LOD) is evaluated in fp64 on the device, so a sample whose
@@ -203,3 +203,64 @@ def test_group_attach_and_debug_entry_points_refuse_bad_arguments(api):
     assert r.lib.rtx_debug_blas_wide(r.ctx, 99, C.byref(need)) == 1
     assert r.lib.rtx_debug_blas_wide(r.ctx, 0, None) == 1
     r_same.group_destroy(); r.group_destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", [{"RTX_DEBUG_FAIL_ITEM_ALLOC": "1"}, {"RTX_PK_ITEM_BYTES": str(5120 * 64 * 48)}, {"RTX_PK_ITEM_BYTES": "0"}])
+def test_item_buffer_fallbacks_keep_the_frame_and_the_return_code(api, knob, monkeypatch):
+    """The split shadow-ray walk's item buffer is bounded (RTX_PK_ITEM_BYTES; a full chunk makes the packet keep its nodes) and optional: when
+    its allocation fails (forced here: a size no device has) the pending HIP error is cleared and the non-split kernel renders the frame —
+    the call must return RTX_OK, rtx_get_stats too, and the frame must be the reference's."""
+    for k, v in knob.items():
+        monkeypatch.setenv(k, v)
+    for name in ("materials_aniso", "tori16"):
+        sc, g = util.load_golden(name)
+        r = api.Renderer(sc)
+        for mode in ({}, {"serial": True}):
+            cmp = util.compare_to_golden(r.render(**mode), g)                 # render() raises on any non-zero status
+            assert cmp["stats_equal"] and cmp["max_abs"] == 0.0 and cmp["n_diff_pixels"] == 0 and cmp["packed_mismatch"] == 0, (knob, name, mode, cmp)
+
+
+@pytest.mark.gpu
+def test_invalid_knob_values_are_ignored(api, monkeypatch):
+    """Knobs are parsed once in rtx_create, validated and clamped: zero / negative / non-numeric values keep the defaults (a zero-size
+    k_shade grid or a negative shift count in the asm walkers would otherwise break production rendering through an inherited variable)."""
+    for k, v in {"RTX_SHADE_GRID": "0", "RTX_PK_DEFER": "-5", "RTX_PK_GROW": "-3", "RTX_PK_SPLIT": "-64", "RTX_PK_DEFER_LEAF": "banana",
+                 "RTX_SLOT_BUDGET": "-1", "RTX_ITEM_GRID": "0", "RTX_PK_GRID_ANY": "-2", "RTX_RESOLVE_BLOCK": "100", "RTX_LANE_FROM_LEVEL_ANY": "-7"}.items():
+        monkeypatch.setenv(k, v)
+    sc, g = util.load_golden("materials_aniso")
+    cmp = util.compare_to_golden(api.Renderer(sc).render(), g)
+    assert cmp["stats_equal"] and cmp["max_abs"] == 0.0 and cmp["packed_mismatch"] == 0, cmp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [20, 40, 62])
+def test_chain_shaped_tlas_takes_the_per_lane_kernels_instead_of_overflowing_the_packet_stack(api, n):
+    """ONE 64-entry packet stack holds the TLAS part and the BLAS part of a walk, where the reference has a stack per BVH.  A degenerate
+    chain-shaped TLAS (depth n - 1, legal for BVH_TRAVERSAL_STACK_SIZE 64) can need more than that: the host knows both depths and must hand
+    such a scene to the per-lane kernels up front — right frame, RTX_OK from rtx_get_stats — instead of dropping pushes and reporting
+    RTX_ERR_LIMIT after a wrong frame."""
+    import orc
+    from pyrtx import host, scene_io as sio
+    sc, _ = util.load_golden("cube")
+    root = sc.blas[0].nodes[0]
+    inst = np.zeros(n, sio.INSTANCE); boxes = np.zeros((n, 6), np.float32)
+    for k in range(n):                                               # cubes on a line receding from the camera, all visible through one another's gaps
+        one, mn, mx = host.instance_update((0.9 * k - 2.0, 0.15 * k, 1.1 * k), (0.0, 0.0, 0.0, 1.0), root["aabb_min"], root["aabb_max"], 0)
+        inst[k] = one[0]; boxes[k, :3] = mn; boxes[k, 3:] = mx
+    nodes = np.zeros(2 * n, sio.BVH_NODE)                            # root 0, (unused 1), level d: pair (2d + 2, 2d + 3) = (leaf of instance d, rest of the chain)
+    for d in range(n - 1):
+        k = 0 if d == 0 else 2 * d + 1
+        nodes[k]["aabb_min"] = boxes[d:, :3].min(axis=0); nodes[k]["aabb_max"] = boxes[d:, 3:].max(axis=0)
+        nodes[k]["left_or_first"] = 2 * d + 2; nodes[k]["count"] = np.uint32((1 + d % 3) << 30).astype(np.int32)          # split axes vary: near / far orders differ per ray
+        leaf = 2 * d + 2
+        nodes[leaf]["aabb_min"] = boxes[d, :3]; nodes[leaf]["aabb_max"] = boxes[d, 3:]; nodes[leaf]["left_or_first"] = d; nodes[leaf]["count"] = 1
+    last = 2 * (n - 1) + 1 if n > 1 else 0
+    nodes[last]["aabb_min"] = boxes[n - 1, :3]; nodes[last]["aabb_max"] = boxes[n - 1, 3:]; nodes[last]["left_or_first"] = n - 1; nodes[last]["count"] = 1
+    sc.instances, sc.tlas_nodes, sc.tlas_indices = inst, nodes, np.arange(n, dtype=np.int32)
+    sc.config["bounces"] = 1
+    r = api.Renderer(sc)
+    ref = orc.OracleScene(sc).render(threads=8)
+    for mode in ({}, {"serial": True}, {"packet_closest": True}):
+        out = r.render(**mode)
+        assert out["stats"] == ref["stats"] and np.array_equal(out["rgb"].view(np.uint32), ref["rgb"].view(np.uint32)), (n, mode)

@@ -21,6 +21,13 @@ GOLDENS = {
     # BVH_VISUALIZE_HEATMAP builds of the reference (Config.h:23, Raytracer.cpp:97-102) on the same two scenes
     "monkey_small_heat": ("monkey_small", "heat", {"heatmap": 1}),
     "materials_heat": ("materials", "heat", {"heatmap": 1, "mip_filter": 1, "texture_mode": 2}),
+    # the remaining Config.h values, each from its own build of the reference (oracle/ref_harness/Makefile TRAVERSAL / TEXMODE / ANISO / BOUNCES):
+    # BVH_TRAVERSE_TREE_NAIVE (Config.h:27), TEXTURE_SAMPLE_MODE_NEAREST (:38), MAX_ANISOTROPY 2 (:55), NUMBER_OF_BOUNCES 1 / 5 (:12)
+    "materials_naive": ("materials", "naive", {"traversal_strategy": 0, "mip_filter": 1, "texture_mode": 2}),
+    "materials_nearest": ("materials", "nearest", {"texture_mode": 0, "mip_filter": 1}),
+    "materials_aniso2": ("materials", "aniso2", {"max_anisotropy": 2.0, "mip_filter": 1, "texture_mode": 2}),
+    "materials_b1": ("materials", "b1", {"bounces": 1, "mip_filter": 1, "texture_mode": 2}),
+    "materials_b5": ("materials", "b5", {"bounces": 5, "mip_filter": 1, "texture_mode": 2}),
     "camera_keys": ("camera_keys", None, {}),
     "dynamic": ("dynamic", None, {}),
     "tori16": ("tori16", None, {}),
