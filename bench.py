@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--detail", type=int, default=1)
     ap.add_argument("--accel", choices=["sbvh", "bvh", "binned"], default="sbvh",
                     help="BLAS builder for the atrium: the reference's SBVH restated (default, BASELINE configs[2]), its plain BVH, or this repo's binned SAH")
+    ap.add_argument("--bounces", type=int, default=3, help="NUMBER_OF_BOUNCES of the atrium workload (BASELINE configs[2]: 3); other values are A/B runs, not the headline")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget (0 disables)")
@@ -253,10 +254,10 @@ def main():
 
     # ---- scene (built on the host by this repo's own tools; identical on every rank) ----------------
     if args.workload == "atrium":
-        sc = host.atrium_scene(args.width, args.height, bounces=3, detail=args.detail, accel=args.accel)
+        sc = host.atrium_scene(args.width, args.height, bounces=args.bounces, detail=args.detail, accel=args.accel)
         workload = (f"atrium-{sc.blas[0].source_triangle_count}tri Sponza-class stand-in (sponza.obj absent from the reference mount), "
                     f"{args.accel.upper()} ({len(sc.blas[0].tri_hot)} refs, {len(sc.blas[0].nodes)} nodes), "
-                    f"{args.width}x{args.height}, 3 lights, reflect/refract depth 3, anisotropic mips")
+                    f"{args.width}x{args.height}, 3 lights, reflect/refract depth {args.bounces}, anisotropic mips")
     else:
         sys.path.insert(0, os.path.join(REPO, "tests"))
         import util

@@ -24,8 +24,8 @@
 #include "rtx_libm.h"
 #include "rtx_texture.h"
 #include "rtx_trace.h"
-#include "rtx_packet.h"
 #include "rtx_shade.h"
+#include "rtx_packet.h"
 #include "rtx_present.h"
 
 #define SLOT_BUDGET (48ll * 1000 * 1000)      // ray slots per batch of tiles (see plan_batch)
@@ -60,6 +60,7 @@ struct Knobs {
     int resolve_block;           // RTX_RESOLVE_BLOCK      k_resolve workgroup size
     int pk4_order;               // RTX_PK4_ORDER          slot order of the 4-wide records (0: smallest stack need first)
     bool merge_any, no_wide, fail_item_alloc;
+    bool fuse_shade;             // RTX_FUSE_SHADE         the closest-hit packet kernel shades its own hits (0: a k_shade launch per level)
 };
 
 struct KernelTime { const char * name; hipEvent_t a, b; };
@@ -283,6 +284,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     K.pk4_order = (int)knob_int("RTX_PK4_ORDER", 1, 0, 1);
     K.merge_any = knob_int("RTX_SERIAL_MERGE_ANY", 1, 0, 1) != 0;       // one-stream mode: ONE shadow-ray launch for all levels after the last shade (0: one per level)
     K.no_wide = knob_int("RTX_PK_WIDE", 1, 0, 1) == 0;                  // 0: binary shadow-ray walk for every mesh
+    K.fuse_shade = knob_int("RTX_FUSE_SHADE", 0, 0, 1) != 0;      // measured: 1.51 vs 1.28 ms per cfg3 frame with three frames in flight: off
     K.fail_item_alloc = knob_int("RTX_DEBUG_FAIL_ITEM_ALLOC", 0, 0, 1) != 0;      // tests: the item buffer's allocation fails (a size no device has), the fallback kernel must take over
     int bpc = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_fast<false>, RTX_TRACE_BLOCK, 0);
@@ -291,7 +293,8 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->trace_blocks_any = c->n_cu * (bpc > 0 ? bpc : 2);
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace<false, true>, RTX_TRACE_BLOCK, 0);
     c->trace_blocks_count = c->n_cu * (bpc > 0 ? bpc : 2);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_packet<false, false>, RTX_PK_BLOCK, 0);
+    if (K.fuse_shade) hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_packet<false, false, false, true, false>, RTX_PK_BLOCK, 0);      // one grid size for every closest-hit packet launch of a context
+    else              hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_packet<false, false>, RTX_PK_BLOCK, 0);
     c->pk_blocks_closest = (c->n_cu * (bpc > 0 ? bpc : 4) + 1) & ~1;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_packet<true, false>, RTX_PK_BLOCK, 0);
     c->pk_blocks_any = (c->n_cu * (bpc > 0 ? bpc : 4) + 1) & ~1;
@@ -316,6 +319,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->q.pk_defer_leaf = (int)knob_int("RTX_PK_DEFER_LEAF", c->q.pk_defer_t0 / 2, 0, 64);
     c->q.pk_defer_t0_closest = (int)knob_int("RTX_PK_DEFER_CLOSEST", 64, 0, 64);
     c->q.pk_order = (int)knob_int("RTX_PK_ORDER", 1, 0, 1);
+    c->q.prof_level = (int)knob_int("RTX_LANE_PROF_LEVEL", 2, 0, RTX_MAX_LEVELS);      // -DRTX_LANE_PROF builds only (tools/lane_prof.py)
     c->q.pk_defer_grow = (int)knob_int("RTX_PK_GROW", 3, 0, 31);
     c->q.spill_threads = (int)max_threads;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast
@@ -590,8 +594,10 @@ static int alloc_queues(rtx_ctx * c, int batch_tiles) {
     const int levels = c->cfg.bounces + 1;
     const long long P = 1024ll * batch_tiles;
     long long total = 0;
+    // fused shading hands out the slots of levels >= 1 in wave-private chunks (rtx_packet.h RTX_PK_CHUNK): every wave of the launch above may leave one partly used
+    const long long chunk_slack = c->knobs.fuse_shade ? (long long)c->pk_blocks_closest * (RTX_PK_BLOCK / RTX_WAVE) * RTX_PK_CHUNK : 0;
     for (int d = 0; d <= RTX_MAX_LEVELS; d++) {
-        long long cap = d < levels ? (P << d) : 0;
+        long long cap = d < levels ? (P << d) + (d > 0 ? chunk_slack : 0) : 0;
         c->q.level_base[d] = (int32_t)total; c->q.level_cap[d] = (int32_t)cap;
         total += cap;
     }
@@ -704,7 +710,9 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
     const int levels = c->cfg.bounces + 1;
     const int stream_blocks = c->n_cu * 8;          // k_resolve (256 threads)
     const int shade_blocks = c->n_cu * c->knobs.shade_grid;      // k_shade (RTX_SHADE_BLOCK = 256 threads, 3 resident blocks per CU at 168 VGPRs)
-    rc = ensure(c, c->d_stats_partial, (size_t)(RTX_MAX_LEVELS + 1) * shade_blocks * 4 * sizeof(uint32_t));
+    const int pk_waves_closest = c->pk_blocks_closest * (RTX_PK_BLOCK / RTX_WAVE);
+    const int stats_stride = shade_blocks > pk_waves_closest ? shade_blocks : pk_waves_closest;      // per level: one entry per k_shade workgroup, or per wave of the fused packet kernel
+    rc = ensure(c, c->d_stats_partial, (size_t)(RTX_MAX_LEVELS + 1) * stats_stride * 4 * sizeof(uint32_t));
     if (rc) return rc;
 
     // Item chunks of the split shadow-ray walk (rtx_packet.h, k_items): one chunk per wave of the packet launch, sized ONCE per call for its
@@ -744,7 +752,8 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         if (pk_closest) q.pk_defer_t0_closest = q.pk_defer_t0;
         q.first_tile = first_tile + done * tile_stride; q.tile_stride = tile_stride; q.tile_count = n; q.primary_slots = n * 1024;
         q.tm_packed = tile_major; q.tm_base = done * 1024;
-        q.stats_partial = (uint32_t *)c->d_stats_partial.p; q.shade_blocks = shade_blocks;
+        q.stats_partial = (uint32_t *)c->d_stats_partial.p; q.stats_stride = stats_stride;
+        for (int d = 0; d <= RTX_MAX_LEVELS; d++) q.stats_n[d] = 0;
         const DevScene sc = c->scene;
         const bool plain = count_work || simple || sc.heatmap;
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, c->stream, q.counters, q.pk_heads, (uint32_t)q.primary_slots,
@@ -781,12 +790,19 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         // instances 1.54 / 2.24 / 3.01 vs 1.66 / 2.41 / 3.05 ms per frame, cfg5 2.32 vs 2.42): shadow rays then stay with the packets
         if (c->knobs.lane_from_level < 0 && c->knobs.split_items > 0 && sc.light_count > 0) { bool all_wide = true; for (size_t b = 0; b < c->h_blas.size(); b++) if (c->h_blas[b].nodes && !c->h_blas[b].pk4_nodes) all_wide = false; if (all_wide) lane_from = RTX_MAX_LEVELS + 1; }
         if (c->knobs.lane_from_level_any >= 0) lane_from = c->knobs.lane_from_level_any;      // shadow rays only (A/B runs)
+        // Which levels shade their own hits inside the closest-hit packet kernel (k_packet<.., FUSE>, rtx_packet.h) and which get a k_shade
+        // launch (every other closest-hit kernel: per-lane, plain, instrumented).  Decided before anything is launched: k_resolve is told
+        // how many partial tallies each level's shading pass leaves (q.stats_n).
+        auto level_is_fused = [&](int level) { return c->knobs.fuse_shade && !count_work && !simple && !pstat && !lane && level < lane_from_closest; };
+        for (int level = 0; level < levels; level++) q.stats_n[level] = level_is_fused(level) ? pk_waves_closest : shade_blocks;
         auto launch_closest = [&](int level) {
-            launch_timed(c, "k_trace_closest", c->stream, [&] {
+            launch_timed(c, level_is_fused(level) ? "k_trace_closest_shade" : "k_trace_closest", c->stream, [&] {
                 if (count_work)     hipLaunchKernelGGL((k_trace<false, true>),   dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (simple)    hipLaunchKernelGGL((k_trace<false, false>),  dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
                 else if (lane || (!pstat && level >= lane_from_closest)) hipLaunchKernelGGL((k_trace_fast<false>),    dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level, level);
                 else if (pstat)     hipLaunchKernelGGL((k_packet<false, true>),  dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
+                else if (level_is_fused(level) && cull) hipLaunchKernelGGL((k_packet<false, false, false, true, true>),  dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
+                else if (level_is_fused(level))         hipLaunchKernelGGL((k_packet<false, false, false, true, false>), dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
                 else                hipLaunchKernelGGL((k_packet<false, false>), dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, level, level);
             });
         };
@@ -816,7 +832,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         };
         for (int level = 0; level < levels; level++) {
             launch_closest(level);
-            launch_timed(c, "k_shade", c->stream, [&] {
+            if (!level_is_fused(level)) launch_timed(c, "k_shade", c->stream, [&] {
                 if (count_work) hipLaunchKernelGGL((k_shade<true, false>),  dim3(shade_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
                 else if (cull)  hipLaunchKernelGGL((k_shade<false, true>),  dim3(shade_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
                 else            hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
@@ -1300,9 +1316,9 @@ __global__ void k_debug_fill_rays(DevQueues q, const float * rays, int n) {
     if (i >= n) return;
     const float * r = rays + 18 * (size_t)i;
     const uint32_t s = (uint32_t)q.level_base[1] + (uint32_t)i;
-    q.r0[s] = make_float4(r[0], r[1], r[2], r[3]); q.r1[s] = make_float4(r[4], r[5], r[6], r[7]);
+    q.r0[s] = make_float4(r[0], r[1], r[2], r[3]); q.r1[s] = make_float4(r[4], r[5], as_f(0), as_f(-1));      // (origin, d.x) (d.y, d.z, pixel, parent)
     q.r2[s] = make_float4(r[8], r[9], r[10], r[11]); q.r3[s] = make_float4(r[12], r[13], r[14], r[15]);
-    q.r4[s] = make_float4(r[16], r[17], 0.0f, 0.0f);
+    q.r4[s] = make_float4(r[16], r[17], r[6], r[7]);
 }
 __global__ void k_debug_rebuild(DevScene sc, DevQueues q, const float * rays, float * out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

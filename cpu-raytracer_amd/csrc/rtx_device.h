@@ -39,6 +39,8 @@ static __device__ __forceinline__ float4 gld(rtx_gptr p, int i) { const rtx_f4v 
 #define NF_REFR     8      // refraction_mask (|Kt|^2 > 0 and bounces left)
 #define NF_TIR      16
 #define NF_ENTER    32
+#define RAY_DEAD_PIXEL (-1)   // ray record r1.z (pixel) of a queue slot that holds no ray: the closest-hit kernels skip it, shading marks its node NF_CLIP
+#define NF_CLIP     64     // the slot holds no ray — a pixel of an edge tile outside the frame (WorkerThread.cpp:60-61) or an unused slot of a wave's chunk: nothing to resolve
 
 struct DevBlas {
     const float4 *            nodes;      // 2 x float4 per node: (min.xyz, left_or_first) (max.xyz, count)   [per-lane kernels, rtx_trace.h]
@@ -110,10 +112,10 @@ struct DevQueues {
 
     // ray records, levels >= 1 (level 0 is regenerated from the pixel index): 5 x float4
     float4 * r0;   // o.x o.y o.z d.x
-    float4 * r1;   // d.y d.z dOdx.x dOdx.y
+    float4 * r1;   // d.y d.z bits(pixel; RAY_DEAD_PIXEL = the slot holds no ray) bits(parent slot | refraction<<31)
     float4 * r2;   // dOdx.z dOdy.x dOdy.y dOdy.z
     float4 * r3;   // dDdx.x dDdx.y dDdx.z dDdy.x
-    float4 * r4;   // dDdy.y dDdy.z bits(pixel) bits(parent slot | refraction<<31)
+    float4 * r4;   // dDdy.y dDdy.z dOdx.x dOdx.y
     // hit records
     float4 *  h0;  // t u v bits(prim)
     int32_t * h1;  // triangle index
@@ -133,6 +135,7 @@ struct DevQueues {
     int32_t *     spill;          // traversal stack spill, 3 regions of [(entry - RTX_LDS_STACK) * spill_threads + thread]: closest entries, closest keys, shadow entries
     int32_t       spill_threads;
     int32_t *     pk_fifo;        // closest-hit hybrid walk: per-lane work lists, [RTX_PK_FIFO entries][spill_threads] (rtx_packet.h)
+    int32_t       prof_level;     // RTX_LANE_PROF builds: the level whose closest-hit launch leaves its phase profile in the work counters
     int32_t       pk_order;       // shadow-ray packets: 1 = last level first (default), 0 = queue order
     int32_t       pk_defer_grow;  // ... threshold = pk_defer_t0 + (steps of this packet walk >> pk_defer_grow)
     int32_t       pk_defer_t0_closest;   // the same threshold for closest-hit packets (64 = every lane walks its ray privately from the BLAS root)
@@ -142,8 +145,9 @@ struct DevQueues {
     uint4 *       pk_items;       // (ray slot, leaf count << 24 | first, instance, -)
     uint32_t *    pk_item_count;  // items in each chunk
     DevCounters * counters;
-    uint32_t *    stats_partial;  // [level][k_shade block][4]: per-block ray tallies, summed by k_resolve(level 0) (no atomics at the end of k_shade)
-    int32_t       shade_blocks;
+    uint32_t *    stats_partial;  // [level][stats_stride][4]: partial ray tallies of the level's shading pass, summed by k_resolve(level 0) (no atomics at the end of the pass)
+    int32_t       stats_stride;   // entries reserved per level
+    int32_t       stats_n[RTX_MAX_LEVELS + 1];     // entries the level's pass writes: k_shade one per workgroup, the fused packet kernel one per wave
     uint32_t *    pk_heads;       // packet-queue heads of the packet kernels: [closest | any][level][8 heads], 128 bytes apart (rtx_packet.h)
     uint32_t *    tm_packed;      // group rendering: level-0 pixels go, packed, to tm_packed[tm_base + primary slot] (tile-major) instead of the raster framebuffer
     int32_t       tm_base;

@@ -36,6 +36,7 @@
 #include "rtx_math.h"
 #include "rtx_device.h"
 #include "rtx_trace.h"
+#include "rtx_shade.h"          // shade_ray: the closest-hit packet kernel shades its own hits (FUSE)
 
 #ifndef RTX_PK_BLOCK
 #define RTX_PK_BLOCK    64           // the waves of a packet launch are independent: one wave per workgroup finds room beside other frames' kernels
@@ -51,6 +52,13 @@
 #endif
 #ifndef RTX_PK_WAVES_CLOSEST
 #define RTX_PK_WAVES_CLOSEST 4
+#endif
+#ifndef RTX_PK_CHUNK
+#define RTX_PK_CHUNK 64u             // FUSE: child-ray slots a wave takes from the next level's queue per atomic (whole 64-slot packets; the unused tail of a wave's last chunk stays empty)
+#endif
+#ifndef RTX_PK_WAVES_FUSED
+#define RTX_PK_WAVES_FUSED 3         // closest-hit walk + shading of the hits in one kernel: shade_ray needs 168 VGPRs; the closest-hit walk does not mind
+                                     // (compiled for 3 / 4 / 5 waves per SIMD it takes 0.828 / 0.839 / 0.934 ms per frame alone)
 #endif
 
 // constant address space + wave-uniform index = scalar load
@@ -133,6 +141,11 @@ struct PkWalk {                      // everything a packet walk carries; wave-u
     unsigned long long st_pairs, st_tris, st_pair_lanes, st_tri_lanes;
 #ifdef RTX_PK_PROF
     unsigned long long prof[10];      // cycles: 0 setup, 1 descend, 2 leaf, 3 pop, 4 results; 5..9 their counts
+#endif
+#ifdef RTX_LANE_PROF
+    // closest-hit per-lane phase of ONE level (RTX_LANE_PROF_LEVEL): where do the dependent steps' microseconds go?  (tools/lane_prof.py)
+    uint32_t lp[16];                  // (kept wave-uniform in SGPRs: every update goes through readfirstlane) 0 phase ticks, 1 iterations, 2 inner steps, 3 leaf steps, 4 pops with a node fetch, 5 work-list reads, 6 triangle round trips,
+                                      // 7 ticks waiting for child pairs, 8 for triangles, 9 for pop / work-list fetches, 10 max phase ticks, 11 max iterations, 12 phases
 #endif
 };
 
@@ -1060,8 +1073,17 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
         else { W.err = 1; return; }
         sp++;
     };
+#ifdef RTX_LANE_PROF
+#define LP_NOW() ({ asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_memtime(); })
+    const unsigned long long lp_t0 = LP_NOW(); unsigned long long lp_it = 0;
+#endif
     for (;;) {
         if (__ballot(have_cur || sp > 0 || fi < fifo_n) == 0ull) break;
+#ifdef RTX_LANE_PROF
+        lp_it++;
+        const bool lp_inner = __ballot(have_cur && (cur_cnt & 0x3fffffff) == 0) != 0ull;
+        const unsigned long long lp_a = LP_NOW();
+#endif
         // inner node: child-pair gather, both slab tests, the lane's own near / far order (BVHNode.h:30-40)
         if (have_cur && (cur_cnt & 0x3fffffff) == 0) {
             const int left = cur_first;
@@ -1088,6 +1110,12 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
             } else if (p_far) { cur_first = far_first; cur_cnt = far_cnt; }
             else have_cur = false;
         }
+#ifdef RTX_LANE_PROF
+        const unsigned long long lp_c = LP_NOW();                  // outside the divergent block: wave-uniform bookkeeping
+        if (lp_inner) { W.lp[2] = (uint32_t)rfl((int)(W.lp[2] + 1u)); W.lp[7] = (uint32_t)rfl((int)(W.lp[7] + (uint32_t)(lp_c - lp_a))); }       // the whole inner block: child-pair gather + two slab tests + push
+        const bool lp_leaf = __ballot(have_cur && (cur_cnt & 0x3fffffff) > 0) != 0ull;
+        if (lp_leaf) W.lp[3] = (uint32_t)rfl((int)(W.lp[3] + 1u));
+#endif
         // leaf: triangle_trace, BottomLevelBVH.cpp:214-309 (hit test; the accept branch is rebuilt by k_shade)
         if (have_cur && (cur_cnt & 0x3fffffff) > 0) {
             have_cur = false;
@@ -1109,6 +1137,13 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
                 tcur = t; W.best_u = u; W.best_v = v; W.best_tri = i; W.best_prim = PRIM_TRI | W.cur_inst;
             }
         }
+#ifdef RTX_LANE_PROF
+        const unsigned long long lp_d = LP_NOW();
+        if (lp_leaf) W.lp[8] = (uint32_t)rfl((int)(W.lp[8] + (uint32_t)(lp_d - lp_c)));
+        const bool lp_popg = __ballot(!have_cur && sp > 0) != 0ull, lp_fifo = __ballot(!have_cur && sp == 0 && fi < fifo_n) != 0ull;
+        if (lp_popg) W.lp[4] = (uint32_t)rfl((int)(W.lp[4] + 1u));
+        if (lp_fifo) W.lp[5] = (uint32_t)rfl((int)(W.lp[5] + 1u));
+#endif
         // pop: the lane's own stack first, then the next entry of its work list
         if (!have_cur) {
             if (sp > 0) {
@@ -1129,7 +1164,18 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
                 if ((e & PK_FIFO_PRETESTED) || slab_test_sel<true>(na, nb, co, cinv, tcur, k)) { cur_first = as_i(na.w); cur_cnt = as_i(nb.w); have_cur = true; }
             }
         }
+#ifdef RTX_LANE_PROF
+        { const unsigned long long lp_f = LP_NOW(); if (lp_popg || lp_fifo) W.lp[9] = (uint32_t)rfl((int)(W.lp[9] + (uint32_t)(lp_f - lp_d))); }
+#endif
     }
+#ifdef RTX_LANE_PROF
+    {
+        const unsigned long long lp_e = LP_NOW();
+        W.lp[0] = (uint32_t)rfl((int)(W.lp[0] + (uint32_t)(lp_e - lp_t0))); W.lp[1] = (uint32_t)rfl((int)(W.lp[1] + (uint32_t)(lp_it))); W.lp[12] = (uint32_t)rfl((int)(W.lp[12] + 1u));
+        if ((uint32_t)(lp_e - lp_t0) > W.lp[10]) W.lp[10] = (uint32_t)rfl((int)(uint32_t)(lp_e - lp_t0));
+        if ((uint32_t)lp_it > W.lp[11]) W.lp[11] = (uint32_t)rfl((int)(uint32_t)lp_it);
+    }
+#endif
     W.ray.tcur = tcur;
     W.fifo_n = 0;
 }
@@ -1307,8 +1353,13 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
     }
 }
 
-template <bool ANY, bool PSTAT, bool SPLIT = false>
-__global__ __launch_bounds__(RTX_PK_BLOCK, ANY ? (SPLIT ? RTX_PK_WAVES_SPLIT : RTX_PK_WAVES_ANY) : RTX_PK_WAVES_CLOSEST)
+// FUSE (closest-hit only): the wave shades the hits of its packet itself (shade_ray, rtx_shade.h) instead of writing hit records for a
+// k_shade launch.  Why: with several frames in flight a k_shade launch (168 VGPRs per wave) waits for room beside the other frames'
+// persistent traversal grids — 0.07 ms of work took 0.29 ms per launch, a third of a frame's time on its stream — while a wave that
+// already owns its slot simply carries on; the hit records' round trip through HBM (20 B per ray each way) and four launches per frame go
+// away too.  Child-ray slots: one atomic per packet that spawns any (wave_alloc2).
+template <bool ANY, bool PSTAT, bool SPLIT = false, bool FUSE = false, bool CULL = false>
+__global__ __launch_bounds__(RTX_PK_BLOCK, ANY ? (SPLIT ? RTX_PK_WAVES_SPLIT : RTX_PK_WAVES_ANY) : (FUSE ? RTX_PK_WAVES_FUSED : RTX_PK_WAVES_CLOSEST))
 void k_packet(const DevScene sc, const DevQueues q, const int level, const int level_hi) {
     // hybrid any-hit walk: the lanes' private stacks, striped through LDS ([entry][lane]: conflict-free)
     // closest-hit: RTX_LDS_STACK entries + their pop-time keys (the per-lane kernels' stack layout, rtx_trace.h)
@@ -1347,11 +1398,36 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
     for (int i = 0; i < 10; i++) W.prof[i] = 0ull;
     const unsigned long long pk_k0_ = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef RTX_LANE_PROF
+    for (int i = 0; i < 16; i++) W.lp[i] = 0u;
+    const unsigned long long lp_k0 = __builtin_amdgcn_s_memtime(), lp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     W.tlas = pk_cptr(sc.pk_tlas_nodes);
     W.err = 0; W.st_pairs = W.st_tris = W.st_pair_lanes = W.st_tri_lanes = 0ull; W.item_n = 0; W.item_slot = 0; W.cur_blas = 0;
     W.st_a = W.st_b = W.st_mlo = W.st_mhi = W.st_idx = W.st_df = 0;
     unsigned long long st_packets = 0ull;
-
+    ShadeTally tally = { 0, 0, 0, 0, 0, 0, 0, 0 };               // FUSE: this wave's ray tallies over all its packets
+    // Child-ray slots come out of wave-private CHUNKS of the next level's queue: one atomic per RTX_PK_CHUNK slots instead of one per packet
+    // (the queue counter sustains ~90 atomics/us: 32 400 packets of a 1080p level-0 launch, each waiting for its own atomic, cost +0.24 ms).
+    // A packet's children fill what is left of the wave's chunk and continue in a fresh one; the slots a wave has not used when it exits
+    // are marked as holding no ray (RAY_DEAD_PIXEL), which every consumer treats like a clipped pixel.
+    uint32_t chunk_next = 0, chunk_end = 0;
+    auto wave_alloc2 = [&](bool want_a, bool want_b, uint32_t * counter, uint32_t & slot_a, uint32_t & slot_b) {
+        const unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
+        const uint32_t ca = (uint32_t)__popcll(ma), need = ca + (uint32_t)__popcll(mb);
+        if (need == 0u) { slot_a = slot_b = 0u; return; }
+        const uint32_t avail = chunk_end - chunk_next, first_base = chunk_next, first_n = need < avail ? need : avail;
+        uint32_t second_base = 0;
+        if (need > avail) {
+            const uint32_t want = need - avail, grab = (want + RTX_PK_CHUNK - 1u) / RTX_PK_CHUNK * RTX_PK_CHUNK;
+            if (lane == 0) second_base = atomicAdd(counter, grab);
+            second_base = (uint32_t)rfl((int)second_base);
+            chunk_next = second_base + want; chunk_end = second_base + grab;
+        } else chunk_next += need;
+        const uint32_t rank_a = (uint32_t)__popcll(ma & ((1ull << lane) - 1ull)), rank_b = ca + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+        slot_a = rank_a < first_n ? first_base + rank_a : second_base + (rank_a - first_n);
+        slot_b = rank_b < first_n ? first_base + rank_b : second_base + (rank_b - first_n);
+    };
     uint32_t cls = gwave & (RTX_PK_CLASSES - 1);
     int probes_left = 2;                       // own head, then one neighbour (steal), then stop
     bool first_round = true;
@@ -1411,7 +1487,8 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
                     else { clipped = true; W.valid = false; }
                 } else {
                     const float4 r0 = q.r0[out_slot], r1 = q.r1[out_slot];
-                    wo = V3(r0.x, r0.y, r0.z); wd = V3(r0.w, r1.x, r1.y);
+                    if (as_i(r1.z) == RAY_DEAD_PIXEL) { clipped = true; W.valid = false; }      // unused slot of a wave's chunk (below): no ray
+                    else { wo = V3(r0.x, r0.y, r0.z); wd = V3(r0.w, r1.x, r1.y); }
                 }
             }
         }
@@ -1470,8 +1547,30 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
         // ---------------- results ----------------
         if (ANY) { if (((alive0 & ~W.alive) >> lane) & 1ull) W.occluded = true; }      // lanes that left the packet were hit
         if (ANY) { if (W.valid) q.socc[out_slot] = W.occluded ? 1u : 0u; }
+        else if (FUSE) {
+            // Raytracer::bounce from the hit on (Raytracer.cpp:104-346), for the packet's 64 rays at once; a clipped pixel's slot exists but holds no ray
+            const bool in_range = W.valid || clipped;
+#ifdef RTX_LANE_PROF
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long sp_t0 = __builtin_amdgcn_s_memtime();
+#endif
+            shade_ray<false, CULL>(sc, q, level, pix_idx, in_range, W.valid, make_float4(W.ray.tcur, W.best_u, W.best_v, as_f(W.best_prim)),
+                                   clipped ? -1 : W.best_tri, wave_alloc2, tally);
+#ifdef RTX_LANE_PROF
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            W.lp[13] = (uint32_t)rfl((int)(W.lp[13] + (uint32_t)(__builtin_amdgcn_s_memtime() - sp_t0))); W.lp[14] = (uint32_t)rfl((int)(W.lp[14] + 1u));
+#endif
+        }
         else if (W.valid) { q.h0[out_slot] = make_float4(W.ray.tcur, W.best_u, W.best_v, as_f(W.best_prim)); q.h1[out_slot] = W.best_tri; }
         else if (clipped) { q.h0[out_slot] = make_float4(INFINITY, 0.0f, 0.0f, as_f(PRIM_NONE)); q.h1[out_slot] = -1; }   // clipped pixel: never shaded
+    }
+    if (!ANY && FUSE && chunk_next < chunk_end) {      // the unused tail of this wave's last chunk (< RTX_PK_CHUNK slots): no ray there
+        const uint32_t dead = chunk_next + (uint32_t)lane;
+        if (dead < chunk_end && dead < (uint32_t)q.level_cap[level + 1])
+            q.r1[(uint32_t)q.level_base[level + 1] + dead] = make_float4(0.0f, 0.0f, as_f(RAY_DEAD_PIXEL), as_f(-1));
+    }
+    if (!ANY && FUSE && lane < 4) {        // this wave's share of the level's ray tallies (every wave writes its entry: q.stats_n[level] = waves of this launch)
+        const uint32_t v = lane == 0 ? tally.n_primary : (lane == 1 ? tally.n_shadow : (lane == 2 ? tally.n_refl : tally.n_refr));
+        q.stats_partial[((size_t)level * q.stats_stride + gwave) * 4 + lane] = v;
     }
 
 #ifdef RTX_PK_PROF
@@ -1479,6 +1578,18 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
     W.prof[7] = __builtin_amdgcn_s_memtime();                    // last end (max)
     W.prof[8] = (1ull << 62) - pk_k0_;                           // first start (max of the complement)
     if (lane == 0) for (int i = 0; i < 10; i++) { if (i == 4 || i == 5 || i == 7 || i == 8 || i == 9) atomicMax(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); else atomicAdd(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); }
+#endif
+#ifdef RTX_LANE_PROF
+    if (!ANY && level == q.prof_level && lane == 0 && W.lp[12] > 0u) {       // waves that walked something (no atomic storm of the idle ones)
+        // wave-uniform values; inner-wait ticks were accumulated by every lane identically
+        for (int i = 0; i < 10; i++) atomicAdd(&ctr->work[i], (unsigned long long)W.lp[i]);
+        atomicMax(&ctr->work[10], (unsigned long long)W.lp[10]); atomicMax(&ctr->work[11], (unsigned long long)W.lp[11]); atomicAdd(&ctr->work[12], (unsigned long long)W.lp[12]);
+        atomicMax(&ctr->work[13], __builtin_amdgcn_s_memtime() - lp_k0);      // longest wave lifetime
+        atomicAdd(&ctr->work[14], __builtin_amdgcn_s_memtime() - lp_k0);
+        atomicAdd(&ctr->work[15], 1ull);                                        // waves
+        atomicAdd(&ctr->work[16], __builtin_amdgcn_s_memrealtime() - lp_r0);
+        atomicAdd(&ctr->work[17], (unsigned long long)W.lp[13]); atomicAdd(&ctr->work[18], (unsigned long long)W.lp[14]);      // fused shading: ticks, packets    // the same lifetimes on the constant 100 MHz clock: calibrates the s_memtime tick
+    }
 #endif
     if (ANY && SPLIT && q.pk_items && lane == 0) { q.pk_item_count[gwave] = (uint32_t)W.item_n; if ((uint32_t)W.item_n > __hip_atomic_load(&ctr->item_max[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ctr->item_max[level], (uint32_t)W.item_n); }      // few waves raise the maximum: one counter sustains only ~90 atomics/us
     if (W.err) { if (lane == 0) atomicOr(&ctr->error_flags, ERR_STACK_OVERFLOW); }

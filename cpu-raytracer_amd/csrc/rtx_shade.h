@@ -160,36 +160,235 @@ RTX_D v3 light_calc(v3 colour, v3 normal, v3 to_light, v3 to_camera) {
 // SpotLight.h:25-26) cannot change the pixel whether or not it is occluded (diffuse + 0 == diffuse).  With CULL the shadow
 // ray is still COUNTED (the reference counts before testing, Raytracer.cpp:163,180,192) but marked so that k_trace<any>
 // retires it without traversal.  Off by default; bench.py reports it as a separate figure.
+
+// wave-uniform tallies of a shading pass (SGPRs): ballot popcounts instead of one VGPR counter per statistic; n_texels is per lane (COUNT builds)
+struct ShadeTally { uint32_t n_shadow, n_refl, n_refr, n_primary, n_shaded, n_sky, n_trihit, n_texels; };
+
+// The shading of ONE ray per lane: everything Raytracer::bounce does between the trace and the recursion (Raytracer.cpp:104-346) for the
+// ray in slot `idx` of `level`, given its closest hit (h0 = distance, u, v, primitive; tri = triangle index, -1 for a clipped pixel).
+// Called with wave-uniform control flow by k_shade (one launch per level, slots allocated per workgroup) and, fused, by the closest-hit
+// packet kernel right after a packet's walk (rtx_packet.h: no h0 / h1 round trip through HBM, no launch of its own to find room for
+// beside other frames' persistent grids).  `valid` = the slot holds a ray; `in_range` = the slot exists (idx < rays of the level).
+// alloc2(want_a, want_b, counter, slot_a, slot_b) hands out the child-ray slots; every lane of the wave must call it.
+template <bool COUNT, bool CULL, typename Alloc2>
+RTX_D void shade_ray(const DevScene & sc, const DevQueues & q, const int level, const uint32_t idx, const bool in_range, bool valid,
+                     const float4 h0, const int tri, Alloc2 && alloc2, ShadeTally & T) {
+    DevCounters * const ctr = q.counters;
+    const int bounces_left = sc.bounces - level;
+    const int nL = sc.light_count;
+    const int lit_cap = q.level_cap[level];
+    const uint32_t slot = (uint32_t)q.level_base[level] + (in_range ? idx : 0u);
+    RayFull ray;
+    int pixel = 0, parent = -1;
+    if (valid && tri == -1) valid = false;                        // a slot without a ray: clipped pixel of an edge tile (level 0), unused tail of a wave's slot chunk (deeper levels)
+    if (valid) {
+        if (level == 0) {
+            int px, py;
+            primary_pixel(sc, q, idx, px, py);
+            primary_ray(sc, px, py, ray, true);
+            pixel = py * sc.width + px;
+        } else {
+            const float4 r0 = q.r0[slot], r1 = q.r1[slot], r2 = q.r2[slot], r3 = q.r3[slot], r4 = q.r4[slot];
+            ray.o = V3(r0.x, r0.y, r0.z); ray.d = V3(r0.w, r1.x, r1.y);
+            ray.dO_dx = V3(r4.z, r4.w, r2.x); ray.dO_dy = V3(r2.y, r2.z, r2.w);
+            ray.dD_dx = V3(r3.x, r3.y, r3.z); ray.dD_dy = V3(r3.w, r4.x, r4.y);
+            pixel = as_i(r1.z); parent = as_i(r1.w);
+        }
+    }
+    if (level == 0) T.n_primary += (uint32_t)__popcll(__ballot(valid));
+    const int prim = as_i(h0.w);
+    const float t = h0.x;
+    const bool is_hit = valid && PRIM_KIND(prim) != PRIM_NONE;
+
+    int flags = 0;
+    v3 albedo = V3(0, 0, 0);
+    HitFull h; h.material_id = 0;
+    h.point = h.normal = h.dO_dx = h.dO_dy = h.dN_dx = h.dN_dy = V3(0, 0, 0);
+    h.u = h.v = h.ds_dx = h.ds_dy = h.dt_dx = h.dt_dy = 0.0f;
+    v3 Ks = V3(0, 0, 0), Kt = V3(0, 0, 0); float ior = 1.0f;
+
+    if (valid && !is_hit) {                                       // Raytracer.cpp:105-111
+        albedo = sky_sample(sc.sky, sc.sky_size, ray.d);
+    }
+    if (is_hit) {
+        flags = NF_HIT;
+        const int kind = PRIM_KIND(prim), pi = PRIM_INDEX(prim);
+        if (kind == PRIM_TRI) rebuild_triangle_hit(sc, pi, tri, t, h0.y, h0.z, ray, h);
+        else if (kind == PRIM_SPHERE) rebuild_sphere_hit(sc, sc.spheres[pi], t, ray, h);
+        else rebuild_plane_hit(sc, sc.planes[pi], t, ray, h);
+
+        const rtx_material & m = sc.materials[h.material_id];     // Material::get_albedo, Material.h:16-22
+        albedo = v3p(m.diffuse);
+        if (m.texture_id >= 0) {
+            TexCtx tc; tc.t = &sc.textures[m.texture_id]; tc.fetches = 0;
+            const bool de = sc.diff_enabled != 0;
+            const v3 tex = texture_sample(tc, sc, h.u, h.v, de ? h.ds_dx : 0.0f, de ? h.ds_dy : 0.0f, de ? h.dt_dx : 0.0f, de ? h.dt_dy : 0.0f);
+            albedo = vmul(albedo, tex);
+            if (COUNT) T.n_texels += tc.fetches;
+        }
+        Ks = v3p(m.reflection); Kt = v3p(m.transmittance); ior = m.index_of_refraction;
+        if (vdot(albedo, albedo) > 0.0f) flags |= NF_LIT;         // Raytracer.cpp:143-145
+    }
+
+    if (COUNT) {
+        T.n_sky += (uint32_t)__popcll(__ballot(valid && !is_hit));
+        T.n_shaded += (uint32_t)__popcll(__ballot(is_hit));
+        T.n_trihit += (uint32_t)__popcll(__ballot(is_hit && PRIM_KIND(prim) == PRIM_TRI));
+    }
+    // ---- shadow rays: one per light for every lit hit, in the hit's OWN slot of the shadow queue (no compaction: a shadow-ray packet
+    // is then the same 64 rays as the packet that found the hits — the same 8x8 pixels at level 0 — and the kernel spends no atomic
+    // here; the few lanes without a lit hit are skipped by the shadow-ray kernels, which read NF_LIT from the node record) ----
+    const bool lit = (flags & NF_LIT) != 0;
+    const int lit_rank = (int)idx;
+    if (lit) {
+        const v3 to_camera = vnormalize(vsub(v3p(sc.cam_pos), h.point));     // Raytracer.cpp:152 (camera, not ray origin)
+        int L = 0;
+        for (int i = 0; i < sc.point_light_count; i++, L++) {                 // :155-169
+            const rtx_point_light & pl = sc.point_lights[i];
+            v3 to_light = vsub(v3p(pl.position), h.point);
+            const float d2 = vdot(to_light, to_light);
+            const float d  = sqrtf(d2);
+            to_light = vdivs(to_light, d);
+            const v3 c = vdivs(light_calc(v3p(pl.colour), h.normal, to_light, to_camera), d2);   // PointLight.h:9-11
+            const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
+            const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
+            q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : d);
+            q.s1[s] = make_float4(to_light.x, to_light.y, to_light.z, 0.0f);
+            q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
+            if (dead) q.socc[s] = 1u;
+        }
+        for (int i = 0; i < sc.spot_light_count; i++, L++) {                  // :172-186
+            const rtx_spot_light & sl = sc.spot_lights[i];
+            v3 to_light = vsub(v3p(sl.position), h.point);
+            const float d2 = vdot(to_light, to_light);
+            const float d  = sqrtf(d2);
+            to_light = vdivs(to_light, d);
+            v3 c = V3(0.0f, 0.0f, 0.0f);                                      // SpotLight.h:17-33
+            const float dt = vdot(to_light, v3p(sl.negative_direction));
+            if (dt > sl.outer_cutoff) {
+                float falloff = (dt - sl.outer_cutoff) / (sl.inner_cutoff - sl.outer_cutoff);
+                falloff = (falloff > 1.0f) ? 1.0f : falloff;
+                c = vmuls(vdivs(light_calc(v3p(sl.colour), h.normal, to_light, to_camera), d2), falloff);
+            }
+            const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
+            const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
+            q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : d);
+            q.s1[s] = make_float4(to_light.x, to_light.y, to_light.z, 0.0f);
+            q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
+            if (dead) q.socc[s] = 1u;
+        }
+        for (int i = 0; i < sc.dir_light_count; i++, L++) {                   // :189-198
+            const rtx_directional_light & dl = sc.dir_lights[i];
+            const v3 nd = v3p(dl.negative_direction);
+            const v3 c = light_calc(v3p(dl.colour), h.normal, nd, to_camera);
+            const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
+            const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
+            q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : INFINITY);
+            q.s1[s] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+            q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
+            if (dead) q.socc[s] = 1u;
+        }
+    }
+    T.n_shadow += (uint32_t)nL * (uint32_t)__popcll(__ballot(lit));           // counted before the occlusion test (:163,180,192)
+
+    // ---- secondary rays (Raytracer.cpp:204-346) ----
+    // Which children exist is decided first (cheap), both kinds get their queue slots from ONE block-wide allocation (one global
+    // atomic per 384 rays: the counter sustains ~90 atomics/us, three per block iteration kept this kernel at that rate), then each
+    // child ray is computed and written, one kind at a time (register pressure).
+    float F_r = 0.0f;
+    v3 absorption = V3(0, 0, 0);
+    const bool deeper = is_hit && bounces_left > 0;
+    const bool reflection_mask = deeper && vdot(Ks, Ks) > 0.0f;
+    const bool refraction_mask = deeper && vdot(Kt, Kt) > 0.0f;
+    bool spawn_refr = false, entering = false;
+    float eta = 1.0f, cos_theta = 0.0f, kk = 0.0f, n_1 = 1.0f, n_2 = 1.0f;
+    if (reflection_mask) flags |= NF_REFL;
+    if (refraction_mask) {
+        flags |= NF_REFR;
+        const float dot = vdot(ray.d, h.normal);
+        entering = dot < 0.0f;
+        const float air = 1.0f;
+        n_1 = entering ? air : ior;
+        n_2 = entering ? ior : air;
+        cos_theta = entering ? (0.0f - dot) : dot;
+        eta = n_1 / n_2;
+        kk = 1.0f - (eta * eta * (1.0f - (cos_theta * cos_theta)));
+        if (entering) flags |= NF_ENTER;
+        if (kk < 0.0f) flags |= NF_TIR;                                       // :310-314
+        else spawn_refr = true;
+    }
+    T.n_refl += (uint32_t)__popcll(__ballot(reflection_mask));
+    T.n_refr += (uint32_t)__popcll(__ballot(spawn_refr));
+    uint32_t ci_refl, ci_refr;
+    alloc2(reflection_mask, spawn_refr, &ctr->ray_count[level + 1], ci_refl, ci_refr);
+    auto write_child = [&](uint32_t ci, const RayFull & cr, uint32_t parent_bits) {
+        if (ci >= (uint32_t)q.level_cap[level + 1]) { atomicOr(&ctr->error_flags, ERR_QUEUE_OVERFLOW); return; }
+        const uint32_t cs = (uint32_t)q.level_base[level + 1] + ci;
+        q.r0[cs] = make_float4(cr.o.x, cr.o.y, cr.o.z, cr.d.x);
+        q.r1[cs] = make_float4(cr.d.y, cr.d.z, as_f(pixel), as_f((int)parent_bits));      // pixel >= 0; pixel == -1 marks a slot no ray was written to (RAY_DEAD_PIXEL)
+        q.r2[cs] = make_float4(cr.dO_dx.z, cr.dO_dy.x, cr.dO_dy.y, cr.dO_dy.z);
+        q.r3[cs] = make_float4(cr.dD_dx.x, cr.dD_dx.y, cr.dD_dx.z, cr.dD_dy.x);
+        q.r4[cs] = make_float4(cr.dD_dy.y, cr.dD_dy.z, cr.dO_dx.x, cr.dO_dx.y);
+    };
+    if (reflection_mask) {
+        RayFull rr;
+        rr.o = h.point;
+        const float dn = vdot(ray.d, h.normal);
+        rr.d = vsub(ray.d, vmuls(h.normal, 2.0f * dn));                       // Math::reflect, Math.h:28-30
+        rr.dO_dx = h.dO_dx; rr.dO_dy = h.dO_dy;
+        const float dDN_dx = vdot(ray.dD_dx, h.normal) + vdot(ray.d, h.dN_dx);
+        const float dDN_dy = vdot(ray.dD_dy, h.normal) + vdot(ray.d, h.dN_dy);
+        rr.dD_dx = vsub(ray.dD_dx, vmuls(vadd(vmuls(h.dN_dx, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dx)), 2.0f));
+        rr.dD_dy = vsub(ray.dD_dy, vmuls(vadd(vmuls(h.dN_dy, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dy)), 2.0f));
+        write_child(ci_refl, rr, slot);
+    }
+    if (spawn_refr) {
+        RayFull rf;
+        const v3 normal = entering ? h.normal : vneg(h.normal);
+        rf.o = h.point;
+        rf.d = vadd(vmuls(ray.d, eta), vmuls(normal, (eta * cos_theta) - sqrtf(kk)));      // Math::refract, Math.h:34-36
+        rf.dO_dx = h.dO_dx; rf.dO_dy = h.dO_dy;
+        const float dDN_dx = vdot(ray.dD_dx, h.normal) + vdot(ray.d, h.dN_dx);
+        const float dDN_dy = vdot(ray.dD_dy, h.normal) + vdot(ray.d, h.dN_dy);
+        const float D_dot_N = -cos_theta;
+        const float Dprime_dot_N = -sqrtf(kk);
+        const float mu = -(eta * cos_theta + Dprime_dot_N);
+        rf.dD_dx = vsub(vmuls(ray.dD_dx, eta), vmuls(vadds(vmul(h.dN_dx, h.normal), mu * D_dot_N), dDN_dx));   // :341-342 literally
+        rf.dD_dy = vsub(vmuls(ray.dD_dy, eta), vmuls(vadds(vmul(h.dN_dy, h.normal), mu * D_dot_N), dDN_dy));
+        absorption = vsub(Kt, V3(1.0f, 1.0f, 1.0f));                          // :350
+        float r_0 = (n_1 - n_2) / (n_1 + n_2);                                // Schlick, :378-391
+        r_0 = r_0 * r_0;
+        float ct = cos_theta;
+        if (n_1 > n_2) ct = 0.0f - vdot(rf.d, normal);
+        const float omc  = 1.0f - ct;
+        const float omc2 = omc * omc;
+        F_r = r_0 + ((1.0f - r_0) * omc2) * (omc2 * omc);
+        write_child(ci_refr, rf, slot | 0x80000000u);
+    }
+
+    if (!valid && in_range) q.n0[slot] = make_float4(0.0f, 0.0f, 0.0f, as_f(NF_CLIP));      // clipped pixel of an edge tile: no hit, no shadow rays; k_resolve skips it
+    if (valid) {
+        q.n0[slot] = make_float4(albedo.x, albedo.y, albedo.z, as_f(flags));
+        if (flags & NF_HIT) {
+            q.n1[slot] = make_float4(Ks.x, Ks.y, Ks.z, F_r);
+            q.n2[slot] = make_float4(absorption.x, absorption.y, absorption.z, t);
+        }
+        q.n3[slot] = make_float4(as_f(lit_rank), as_f(pixel), as_f(parent), 0.0f);
+    }
+}
+
 template <bool COUNT, bool CULL>
 __global__ __launch_bounds__(RTX_SHADE_BLOCK, RTX_WAVES_SHADE)
 void k_shade(const DevScene sc, const DevQueues q, const int level) {
     DevCounters * const ctr = q.counters;
     const uint32_t count = ctr->ray_count[level];
     const int lane = threadIdx.x & 63;
-    const int bounces_left = sc.bounces - level;
-    const int nL = sc.light_count;
     // Block-level compaction: every wave publishes its popcount in LDS, one thread performs the global atomicAdd for the
     // whole workgroup, each lane's slot = block base + counts of the lower waves + its popcount-prefix rank.  (One atomic
     // per WAVE kept k_shade at the ~90 atomics/us a single counter sustains: 32 k waves x 3 counters at level 0.)
     __shared__ uint32_t s_wave_cnt[RTX_SHADE_BLOCK / 64];
     __shared__ uint32_t s_block_base;
     const int wave_in_block = threadIdx.x >> 6;
-    auto block_alloc = [&](bool want, uint32_t * counter) -> uint32_t {
-        const unsigned long long m = __ballot(want);
-        if (lane == 0) s_wave_cnt[wave_in_block] = (uint32_t)__popcll(m);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t tot = 0;
-            for (int w = 0; w < RTX_SHADE_BLOCK / 64; w++) tot += s_wave_cnt[w];
-            s_block_base = tot ? atomicAdd(counter, tot) : 0u;
-        }
-        __syncthreads();
-        uint32_t off = s_block_base;
-        for (int w = 0; w < wave_in_block; w++) off += s_wave_cnt[w];
-        const uint32_t r = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        __syncthreads();                          // s_wave_cnt / s_block_base are reused by the next allocation
-        return r;
-    };
     // two kinds of slots from ONE allocation: per block [all `a` slots in lane order][all `b` slots in lane order]
     auto block_alloc2 = [&](bool want_a, bool want_b, uint32_t * counter, uint32_t & slot_a, uint32_t & slot_b) {
         const unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
@@ -207,233 +406,31 @@ void k_shade(const DevScene sc, const DevQueues q, const int level) {
         slot_b = s_block_base + tot_a + off_b + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
         __syncthreads();                          // s_wave_cnt / s_block_base are reused by the next iteration
     };
-    const int lit_cap = q.level_cap[level];
-    // wave-uniform tallies (SGPRs): ballot popcounts instead of one VGPR counter per statistic
-    uint32_t n_shadow = 0, n_refl = 0, n_refr = 0, n_primary = 0, n_shaded = 0, n_sky = 0, n_trihit = 0;
-    uint32_t n_texels = 0;      // per lane, COUNT builds only
-
+    ShadeTally T = { 0, 0, 0, 0, 0, 0, 0, 0 };
     for (uint32_t bbase = blockIdx.x * RTX_SHADE_BLOCK; bbase < count; bbase += gridDim.x * RTX_SHADE_BLOCK) {   // block-uniform trip count
         const uint32_t idx = bbase + threadIdx.x;
-        bool valid = idx < count;
-        const uint32_t slot = (uint32_t)q.level_base[level] + (valid ? idx : 0u);
-
-        RayFull ray;
-        int pixel = 0, parent = -1;
+        const bool valid = idx < count;
         float4 h0 = make_float4(0, 0, 0, 0); int tri = 0;
-        if (valid) { h0 = q.h0[slot]; tri = q.h1[slot]; }
-        if (valid && level == 0 && tri == -1) valid = false;          // clipped pixel of an edge tile
-        if (valid) {
-            if (level == 0) {
-                int px, py;
-                primary_pixel(sc, q, idx, px, py);
-                primary_ray(sc, px, py, ray, true);
-                pixel = py * sc.width + px;
-            } else {
-                const float4 r0 = q.r0[slot], r1 = q.r1[slot], r2 = q.r2[slot], r3 = q.r3[slot], r4 = q.r4[slot];
-                ray.o = V3(r0.x, r0.y, r0.z); ray.d = V3(r0.w, r1.x, r1.y);
-                ray.dO_dx = V3(r1.z, r1.w, r2.x); ray.dO_dy = V3(r2.y, r2.z, r2.w);
-                ray.dD_dx = V3(r3.x, r3.y, r3.z); ray.dD_dy = V3(r3.w, r4.x, r4.y);
-                pixel = as_i(r4.z); parent = as_i(r4.w);
-            }
-        }
-        if (level == 0) n_primary += (uint32_t)__popcll(__ballot(valid));
-        const int prim = as_i(h0.w);
-        const float t = h0.x;
-        const bool is_hit = valid && PRIM_KIND(prim) != PRIM_NONE;
-
-        int flags = 0;
-        v3 albedo = V3(0, 0, 0);
-        HitFull h; h.material_id = 0;
-        h.point = h.normal = h.dO_dx = h.dO_dy = h.dN_dx = h.dN_dy = V3(0, 0, 0);
-        h.u = h.v = h.ds_dx = h.ds_dy = h.dt_dx = h.dt_dy = 0.0f;
-        v3 Ks = V3(0, 0, 0), Kt = V3(0, 0, 0); float ior = 1.0f;
-
-        if (valid && !is_hit) {                                       // Raytracer.cpp:105-111
-            albedo = sky_sample(sc.sky, sc.sky_size, ray.d);
-        }
-        if (is_hit) {
-            flags = NF_HIT;
-            const int kind = PRIM_KIND(prim), pi = PRIM_INDEX(prim);
-            if (kind == PRIM_TRI) rebuild_triangle_hit(sc, pi, tri, t, h0.y, h0.z, ray, h);
-            else if (kind == PRIM_SPHERE) rebuild_sphere_hit(sc, sc.spheres[pi], t, ray, h);
-            else rebuild_plane_hit(sc, sc.planes[pi], t, ray, h);
-
-            const rtx_material & m = sc.materials[h.material_id];     // Material::get_albedo, Material.h:16-22
-            albedo = v3p(m.diffuse);
-            if (m.texture_id >= 0) {
-                TexCtx tc; tc.t = &sc.textures[m.texture_id]; tc.fetches = 0;
-                const bool de = sc.diff_enabled != 0;
-                const v3 tex = texture_sample(tc, sc, h.u, h.v, de ? h.ds_dx : 0.0f, de ? h.ds_dy : 0.0f, de ? h.dt_dx : 0.0f, de ? h.dt_dy : 0.0f);
-                albedo = vmul(albedo, tex);
-                if (COUNT) n_texels += tc.fetches;
-            }
-            Ks = v3p(m.reflection); Kt = v3p(m.transmittance); ior = m.index_of_refraction;
-            if (vdot(albedo, albedo) > 0.0f) flags |= NF_LIT;         // Raytracer.cpp:143-145
-        }
-
-        if (COUNT) {
-            n_sky += (uint32_t)__popcll(__ballot(valid && !is_hit));
-            n_shaded += (uint32_t)__popcll(__ballot(is_hit));
-            n_trihit += (uint32_t)__popcll(__ballot(is_hit && PRIM_KIND(prim) == PRIM_TRI));
-        }
-        // ---- shadow rays: one per light for every lit hit, in the hit's OWN slot of the shadow queue (no compaction: a shadow-ray packet
-        // is then the same 64 rays as the packet that found the hits — the same 8x8 pixels at level 0 — and the kernel spends no atomic
-        // here; the few lanes without a lit hit are skipped by the shadow-ray kernels, which read NF_LIT from the node record) ----
-        const bool lit = (flags & NF_LIT) != 0;
-        const int lit_rank = (int)idx;
-        if (lit) {
-            const v3 to_camera = vnormalize(vsub(v3p(sc.cam_pos), h.point));     // Raytracer.cpp:152 (camera, not ray origin)
-            int L = 0;
-            for (int i = 0; i < sc.point_light_count; i++, L++) {                 // :155-169
-                const rtx_point_light & pl = sc.point_lights[i];
-                v3 to_light = vsub(v3p(pl.position), h.point);
-                const float d2 = vdot(to_light, to_light);
-                const float d  = sqrtf(d2);
-                to_light = vdivs(to_light, d);
-                const v3 c = vdivs(light_calc(v3p(pl.colour), h.normal, to_light, to_camera), d2);   // PointLight.h:9-11
-                const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
-                const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
-                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : d);
-                q.s1[s] = make_float4(to_light.x, to_light.y, to_light.z, 0.0f);
-                q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
-                if (dead) q.socc[s] = 1u;
-            }
-            for (int i = 0; i < sc.spot_light_count; i++, L++) {                  // :172-186
-                const rtx_spot_light & sl = sc.spot_lights[i];
-                v3 to_light = vsub(v3p(sl.position), h.point);
-                const float d2 = vdot(to_light, to_light);
-                const float d  = sqrtf(d2);
-                to_light = vdivs(to_light, d);
-                v3 c = V3(0.0f, 0.0f, 0.0f);                                      // SpotLight.h:17-33
-                const float dt = vdot(to_light, v3p(sl.negative_direction));
-                if (dt > sl.outer_cutoff) {
-                    float falloff = (dt - sl.outer_cutoff) / (sl.inner_cutoff - sl.outer_cutoff);
-                    falloff = (falloff > 1.0f) ? 1.0f : falloff;
-                    c = vmuls(vdivs(light_calc(v3p(sl.colour), h.normal, to_light, to_camera), d2), falloff);
-                }
-                const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
-                const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
-                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : d);
-                q.s1[s] = make_float4(to_light.x, to_light.y, to_light.z, 0.0f);
-                q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
-                if (dead) q.socc[s] = 1u;
-            }
-            for (int i = 0; i < sc.dir_light_count; i++, L++) {                   // :189-198
-                const rtx_directional_light & dl = sc.dir_lights[i];
-                const v3 nd = v3p(dl.negative_direction);
-                const v3 c = light_calc(v3p(dl.colour), h.normal, nd, to_camera);
-                const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
-                const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
-                q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : INFINITY);
-                q.s1[s] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-                q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
-                if (dead) q.socc[s] = 1u;
-            }
-        }
-        n_shadow += (uint32_t)nL * (uint32_t)__popcll(__ballot(lit));           // counted before the occlusion test (:163,180,192)
-
-        // ---- secondary rays (Raytracer.cpp:204-346) ----
-        // Which children exist is decided first (cheap), both kinds get their queue slots from ONE block-wide allocation (one global
-        // atomic per 384 rays: the counter sustains ~90 atomics/us, three per block iteration kept this kernel at that rate), then each
-        // child ray is computed and written, one kind at a time (register pressure).
-        float F_r = 0.0f;
-        v3 absorption = V3(0, 0, 0);
-        const bool deeper = is_hit && bounces_left > 0;
-        const bool reflection_mask = deeper && vdot(Ks, Ks) > 0.0f;
-        const bool refraction_mask = deeper && vdot(Kt, Kt) > 0.0f;
-        bool spawn_refr = false, entering = false;
-        float eta = 1.0f, cos_theta = 0.0f, kk = 0.0f, n_1 = 1.0f, n_2 = 1.0f;
-        if (reflection_mask) flags |= NF_REFL;
-        if (refraction_mask) {
-            flags |= NF_REFR;
-            const float dot = vdot(ray.d, h.normal);
-            entering = dot < 0.0f;
-            const float air = 1.0f;
-            n_1 = entering ? air : ior;
-            n_2 = entering ? ior : air;
-            cos_theta = entering ? (0.0f - dot) : dot;
-            eta = n_1 / n_2;
-            kk = 1.0f - (eta * eta * (1.0f - (cos_theta * cos_theta)));
-            if (entering) flags |= NF_ENTER;
-            if (kk < 0.0f) flags |= NF_TIR;                                       // :310-314
-            else spawn_refr = true;
-        }
-        n_refl += (uint32_t)__popcll(__ballot(reflection_mask));
-        n_refr += (uint32_t)__popcll(__ballot(spawn_refr));
-        uint32_t ci_refl, ci_refr;
-        block_alloc2(reflection_mask, spawn_refr, &ctr->ray_count[level + 1], ci_refl, ci_refr);
-        auto write_child = [&](uint32_t ci, const RayFull & cr, uint32_t parent_bits) {
-            if (ci >= (uint32_t)q.level_cap[level + 1]) { atomicOr(&ctr->error_flags, ERR_QUEUE_OVERFLOW); return; }
-            const uint32_t cs = (uint32_t)q.level_base[level + 1] + ci;
-            q.r0[cs] = make_float4(cr.o.x, cr.o.y, cr.o.z, cr.d.x);
-            q.r1[cs] = make_float4(cr.d.y, cr.d.z, cr.dO_dx.x, cr.dO_dx.y);
-            q.r2[cs] = make_float4(cr.dO_dx.z, cr.dO_dy.x, cr.dO_dy.y, cr.dO_dy.z);
-            q.r3[cs] = make_float4(cr.dD_dx.x, cr.dD_dx.y, cr.dD_dx.z, cr.dD_dy.x);
-            q.r4[cs] = make_float4(cr.dD_dy.y, cr.dD_dy.z, as_f(pixel), as_f((int)parent_bits));
-        };
-        if (reflection_mask) {
-            RayFull rr;
-            rr.o = h.point;
-            const float dn = vdot(ray.d, h.normal);
-            rr.d = vsub(ray.d, vmuls(h.normal, 2.0f * dn));                       // Math::reflect, Math.h:28-30
-            rr.dO_dx = h.dO_dx; rr.dO_dy = h.dO_dy;
-            const float dDN_dx = vdot(ray.dD_dx, h.normal) + vdot(ray.d, h.dN_dx);
-            const float dDN_dy = vdot(ray.dD_dy, h.normal) + vdot(ray.d, h.dN_dy);
-            rr.dD_dx = vsub(ray.dD_dx, vmuls(vadd(vmuls(h.dN_dx, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dx)), 2.0f));
-            rr.dD_dy = vsub(ray.dD_dy, vmuls(vadd(vmuls(h.dN_dy, vdot(ray.d, h.normal)), vmuls(h.normal, dDN_dy)), 2.0f));
-            write_child(ci_refl, rr, slot);
-        }
-        if (spawn_refr) {
-            RayFull rf;
-            const v3 normal = entering ? h.normal : vneg(h.normal);
-            rf.o = h.point;
-            rf.d = vadd(vmuls(ray.d, eta), vmuls(normal, (eta * cos_theta) - sqrtf(kk)));      // Math::refract, Math.h:34-36
-            rf.dO_dx = h.dO_dx; rf.dO_dy = h.dO_dy;
-            const float dDN_dx = vdot(ray.dD_dx, h.normal) + vdot(ray.d, h.dN_dx);
-            const float dDN_dy = vdot(ray.dD_dy, h.normal) + vdot(ray.d, h.dN_dy);
-            const float D_dot_N = -cos_theta;
-            const float Dprime_dot_N = -sqrtf(kk);
-            const float mu = -(eta * cos_theta + Dprime_dot_N);
-            rf.dD_dx = vsub(vmuls(ray.dD_dx, eta), vmuls(vadds(vmul(h.dN_dx, h.normal), mu * D_dot_N), dDN_dx));   // :341-342 literally
-            rf.dD_dy = vsub(vmuls(ray.dD_dy, eta), vmuls(vadds(vmul(h.dN_dy, h.normal), mu * D_dot_N), dDN_dy));
-            absorption = vsub(Kt, V3(1.0f, 1.0f, 1.0f));                          // :350
-            float r_0 = (n_1 - n_2) / (n_1 + n_2);                                // Schlick, :378-391
-            r_0 = r_0 * r_0;
-            float ct = cos_theta;
-            if (n_1 > n_2) ct = 0.0f - vdot(rf.d, normal);
-            const float omc  = 1.0f - ct;
-            const float omc2 = omc * omc;
-            F_r = r_0 + ((1.0f - r_0) * omc2) * (omc2 * omc);
-            write_child(ci_refr, rf, slot | 0x80000000u);
-        }
-
-        if (!valid && idx < count) q.n0[slot] = make_float4(0.0f, 0.0f, 0.0f, as_f(0));      // clipped pixel of an edge tile: no hit, no shadow rays
-        if (valid) {
-            q.n0[slot] = make_float4(albedo.x, albedo.y, albedo.z, as_f(flags));
-            if (flags & NF_HIT) {
-                q.n1[slot] = make_float4(Ks.x, Ks.y, Ks.z, F_r);
-                q.n2[slot] = make_float4(absorption.x, absorption.y, absorption.z, t);
-            }
-            q.n3[slot] = make_float4(as_f(lit_rank), as_f(pixel), as_f(parent), 0.0f);
-        }
+        if (valid) { const uint32_t slot = (uint32_t)q.level_base[level] + idx; h0 = q.h0[slot]; tri = q.h1[slot]; }
+        shade_ray<COUNT, CULL>(sc, q, level, idx, valid, valid, h0, tri, block_alloc2, T);
     }
-
     // statistics: the tallies are per-wave sums; the block adds them up in LDS and ONE thread hands them on.  (One atomic per wave and
     // counter was 20 000 atomics on one cache line at the end of every level-0 launch: at the ~90 atomics/us that line sustains, two
     // thirds of this kernel's time.)  Per-block partial sums go to HBM without any atomic; k_resolve(level 0) adds them into the frame's
     // PerformanceStats.
+    uint32_t n_texels = T.n_texels;
     if (COUNT) for (int off = 32; off > 0; off >>= 1) n_texels += __shfl_down(n_texels, off);
     __shared__ uint32_t s_tally[RTX_SHADE_BLOCK / 64][10];
     if (lane == 0) {
         uint32_t * tw = s_tally[wave_in_block];
-        tw[0] = n_primary; tw[1] = n_shadow; tw[2] = n_refl; tw[3] = n_refr;
-        tw[4] = n_shaded; tw[5] = n_sky; tw[6] = n_texels; tw[7] = n_trihit;
+        tw[0] = T.n_primary; tw[1] = T.n_shadow; tw[2] = T.n_refl; tw[3] = T.n_refr;
+        tw[4] = T.n_shaded; tw[5] = T.n_sky; tw[6] = n_texels; tw[7] = T.n_trihit;
     }
     __syncthreads();
     if (threadIdx.x < 8) {
         uint32_t tot = 0;
         for (int w = 0; w < RTX_SHADE_BLOCK / 64; w++) tot += s_tally[w][threadIdx.x];
-        if (threadIdx.x < 4) q.stats_partial[((size_t)level * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = tot;
+        if (threadIdx.x < 4) q.stats_partial[((size_t)level * q.stats_stride + blockIdx.x) * 4 + threadIdx.x] = tot;      // this launch writes entries 0 .. gridDim.x - 1 = q.stats_n[level]
         else if (COUNT && tot) {
             const int wi[4] = { W_SHADED, W_SKY, W_TEXELS, W_TRI_HITS };
             atomicAdd(&ctr->work[wi[threadIdx.x - 4]], (unsigned long long)tot);
@@ -480,12 +477,12 @@ void k_resolve(const DevScene sc, const DevQueues q, const int level) {
     DevCounters * const ctr = q.counters;
     if (level == 0 && blockIdx.x == 0 && threadIdx.x < 64) {
         // PerformanceStats of this batch: the per-block partial sums of every level's k_shade launch (WorkerThread.cpp:131-148 sums per thread)
-        const int n = (sc.bounces + 1) * q.shade_blocks;
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        for (int i = threadIdx.x; i < n; i += 64) {
-            const uint32_t * p = q.stats_partial + (size_t)i * 4;
-            t0 += p[0]; t1 += p[1]; t2 += p[2]; t3 += p[3];
-        }
+        for (int l = 0; l <= sc.bounces; l++)                          // level l's shading pass wrote q.stats_n[l] entries (k_shade: one per workgroup; fused into the packet kernel: one per wave)
+            for (int i = threadIdx.x; i < q.stats_n[l]; i += 64) {
+                const uint32_t * p = q.stats_partial + ((size_t)l * q.stats_stride + i) * 4;
+                t0 += p[0]; t1 += p[1]; t2 += p[2]; t3 += p[3];
+            }
         for (int off = 32; off > 0; off >>= 1) { t0 += __shfl_down(t0, off); t1 += __shfl_down(t1, off); t2 += __shfl_down(t2, off); t3 += __shfl_down(t3, off); }
         if (threadIdx.x == 0) { atomicAdd(&ctr->stats[0], t0); atomicAdd(&ctr->stats[1], t1); atomicAdd(&ctr->stats[2], t2); atomicAdd(&ctr->stats[3], t3); }
     }
@@ -495,9 +492,10 @@ void k_resolve(const DevScene sc, const DevQueues q, const int level) {
     const int lit_cap = q.level_cap[level];
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
         const uint32_t slot = (uint32_t)q.level_base[level] + idx;
-        if (level == 0 && q.h1[slot] == -1) continue;                 // clipped pixel
-        const float4 n0 = q.n0[slot], n3 = q.n3[slot];
+        const float4 n0 = q.n0[slot];
         const int flags = as_i(n0.w);
+        if (flags & NF_CLIP) continue;                                // clipped pixel of an edge tile
+        const float4 n3 = q.n3[slot];
         v3 colour; float distance;
         if (!(flags & NF_HIT)) {
             colour = V3(n0.x, n0.y, n0.z);                             // sky, Raytracer.cpp:106-110

@@ -260,6 +260,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
                     } else {
                         const float4 r0 = q.r0[out_slot], r1 = q.r1[out_slot];
                         wo = V3(r0.x, r0.y, r0.z); wd = V3(r0.w, r1.x, r1.y);
+                        live = as_i(r1.z) != RAY_DEAD_PIXEL;          // unused slot of a wave's chunk (fused shading of the level above)
                     }
                     tcur = INFINITY;
                     best_prim = PRIM_NONE; best_tri = 0; best_u = 0.0f; best_v = 0.0f; bvh_steps = 0;
@@ -503,6 +504,7 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
                     } else {
                         const float4 r0 = q.r0[out_slot], r1 = q.r1[out_slot];
                         wo = V3(r0.x, r0.y, r0.z); wd = V3(r0.w, r1.x, r1.y);
+                        live = as_i(r1.z) != RAY_DEAD_PIXEL;
                     }
                     tcur = INFINITY;
                     best_prim = PRIM_NONE; best_tri = 0; best_u = 0.0f; best_v = 0.0f;
