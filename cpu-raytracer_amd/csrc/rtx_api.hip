@@ -794,7 +794,11 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         // launch (every other closest-hit kernel: per-lane, plain, instrumented).  Decided before anything is launched: k_resolve is told
         // how many partial tallies each level's shading pass leaves (q.stats_n).
         auto level_is_fused = [&](int level) { return c->knobs.fuse_shade && !count_work && !simple && !pstat && !lane && level < lane_from_closest; };
-        for (int level = 0; level < levels; level++) q.stats_n[level] = level_is_fused(level) ? pk_waves_closest : shade_blocks;
+        // Grids of the streaming kernels (k_shade, k_resolve: grid-stride loops, any grid is correct) follow the batch: level d of a batch of P
+        // primary slots is given room for P / 2^d rays — the dispatcher spends ~16 ns per workgroup, which is most of a small launch's
+        // time (a 1/8 tile shard's k_shade launches of levels 1-3: 18 us each with 1 024 workgroups for 74 k / 6 k / 1 k rays).
+        auto level_blocks = [&](int level, int full) { const long long want = (((long long)q.primary_slots >> level) + 255) / 256; return (int)std::max(64ll, std::min((long long)full, want)); };
+        for (int level = 0; level < levels; level++) q.stats_n[level] = level_is_fused(level) ? pk_waves_closest : level_blocks(level, shade_blocks);
         auto launch_closest = [&](int level) {
             launch_timed(c, level_is_fused(level) ? "k_trace_closest_shade" : "k_trace_closest", c->stream, [&] {
                 if (count_work)     hipLaunchKernelGGL((k_trace<false, true>),   dim3(c->trace_blocks_count), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, level);
@@ -833,9 +837,10 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         for (int level = 0; level < levels; level++) {
             launch_closest(level);
             if (!level_is_fused(level)) launch_timed(c, "k_shade", c->stream, [&] {
-                if (count_work) hipLaunchKernelGGL((k_shade<true, false>),  dim3(shade_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
-                else if (cull)  hipLaunchKernelGGL((k_shade<false, true>),  dim3(shade_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
-                else            hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_blocks), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
+                const int g = level_blocks(level, shade_blocks);
+                if (count_work) hipLaunchKernelGGL((k_shade<true, false>),  dim3(g), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
+                else if (cull)  hipLaunchKernelGGL((k_shade<false, true>),  dim3(g), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
+                else            hipLaunchKernelGGL((k_shade<false, false>), dim3(g), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);
             });
             if (sc.light_count == 0) continue;
             if (overlap) {
@@ -856,7 +861,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         }
         if (overlap) { hipEventRecord(c->ev_any_done, c->any_stream); hipStreamWaitEvent(c->stream, c->ev_any_done, 0); }
         for (int level = levels - 1; level >= 0; level--)
-            launch_timed(c, "k_resolve", c->stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(stream_blocks * (256 / c->knobs.resolve_block)), dim3(c->knobs.resolve_block), 0, c->stream, sc, q, level); });
+            launch_timed(c, "k_resolve", c->stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(level_blocks(level, stream_blocks) * (256 / c->knobs.resolve_block)), dim3(c->knobs.resolve_block), 0, c->stream, sc, q, level); });
     }
     HIP_OK(c, hipGetLastError());
     c->stats_pending = true;

@@ -15,6 +15,12 @@ typedef float rtx_f4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) rtx_f4v * rtx_gptr;
 #define RTX_GPTR(p) ((rtx_gptr)(const void *)(p))
 static __device__ __forceinline__ float4 gld(rtx_gptr p, int i) { const rtx_f4v v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+// the first 12 bytes of 16-byte record i (global_load_dwordx3: a float3 out of a padded record costs three registers, not four)
+typedef float rtx_f3v __attribute__((ext_vector_type(3)));
+static __device__ __forceinline__ float3 gld3(rtx_gptr p, int i) {
+    const rtx_f3v v = *(const __attribute__((address_space(1))) rtx_f3v *)(p + i);
+    return make_float3(v.x, v.y, v.z);
+}
 
 #define RTX_MAX_LEVELS   12          // NUMBER_OF_BOUNCES + 1 wavefront levels supported
 #ifndef RTX_LDS_STACK

@@ -1119,22 +1119,33 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
         // leaf: triangle_trace, BottomLevelBVH.cpp:214-309 (hit test; the accept branch is rebuilt by k_shade)
         if (have_cur && (cur_cnt & 0x3fffffff) > 0) {
             have_cur = false;
-            const int cnt = cur_cnt & 0x3fffffff;
-            for (int i = cur_first; i < cur_first + cnt; i++) {
-                const float4 p0 = gld(tris, RTX_TRI_STRIDE * i), e1 = gld(tris, RTX_TRI_STRIDE * i + 1), e2 = gld(tris, RTX_TRI_STRIDE * i + 2);
-                const v3 edge_1 = V3(e1.x, e1.y, e1.z), edge_2 = V3(e2.x, e2.y, e2.z);
-                const v3 h = vcross(cd, edge_2);
-                const float a = vdot(edge_1, h);
-                const float f = 1.0f / a;
-                const v3 s = vsub(co, V3(p0.x, p0.y, p0.z));
-                const float u = f * vdot(s, h);
-                if (!((u > 0.0f) & (u < 1.0f))) continue;
-                const v3 qq = vcross(s, edge_1);
-                const float v = f * vdot(cd, qq);
-                if (!((v > 0.0f) & ((u + v) < 1.0f))) continue;
-                const float t = f * vdot(edge_2, qq);
-                if (!((t > RAY_EPSILON) & (t < tcur))) continue;
-                tcur = t; W.best_u = u; W.best_v = v; W.best_tri = i; W.best_prim = PRIM_TRI | W.cur_inst;
+            const int end = cur_first + (cur_cnt & 0x3fffffff);
+            // Two triangles per round trip: the reference's SBVH leaves hold two triangles (93 % of the cfg3 tree's), and a lane's walk is a chain
+            // of dependent fetches — the second triangle's record (the next 64 bytes) travels with the first's.  They are still TESTED one after
+            // the other, the second against the closest distance the first may have just set: the reference's loop, BottomLevelBVH.cpp:376-379.
+            for (int i = cur_first; i < end; i += 2) {
+                const bool two = i + 1 < end;
+                const int j = two ? i + 1 : i;
+                const float3 p0 = gld3(tris, RTX_TRI_STRIDE * i), e1 = gld3(tris, RTX_TRI_STRIDE * i + 1), e2 = gld3(tris, RTX_TRI_STRIDE * i + 2);
+                const float3 q0 = gld3(tris, RTX_TRI_STRIDE * j), f1 = gld3(tris, RTX_TRI_STRIDE * j + 1), f2 = gld3(tris, RTX_TRI_STRIDE * j + 2);
+                __builtin_amdgcn_sched_barrier(0);          // all six loads are issued before the first use (the scheduler had put the first test between the two triangles' loads)
+                auto test = [&](const float3 & a0, const float3 & a1, const float3 & a2, const int idx) {
+                    const v3 edge_1 = V3(a1.x, a1.y, a1.z), edge_2 = V3(a2.x, a2.y, a2.z);
+                    const v3 h = vcross(cd, edge_2);
+                    const float a = vdot(edge_1, h);
+                    const float f = 1.0f / a;
+                    const v3 s = vsub(co, V3(a0.x, a0.y, a0.z));
+                    const float u = f * vdot(s, h);
+                    if (!((u > 0.0f) & (u < 1.0f))) return;
+                    const v3 qq = vcross(s, edge_1);
+                    const float v = f * vdot(cd, qq);
+                    if (!((v > 0.0f) & ((u + v) < 1.0f))) return;
+                    const float t = f * vdot(edge_2, qq);
+                    if (!((t > RAY_EPSILON) & (t < tcur))) return;
+                    tcur = t; W.best_u = u; W.best_v = v; W.best_tri = idx; W.best_prim = PRIM_TRI | W.cur_inst;
+                };
+                test(p0, e1, e2, i);
+                if (two) test(q0, f1, f2, j);
             }
         }
 #ifdef RTX_LANE_PROF
