@@ -151,6 +151,121 @@ def reference_cpu_baseline(args, rays_per_frame, stats):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def shade_bytes(work, stats, lights):
+    """Algorithmic bytes of one frame's k_shade launches (DESIGN.md 4): what Raytracer::bounce reads and writes between the trace and the
+    recursion, at the sizes of this repo's queue records.  Reads: hit record 20 B per ray, the ray record 80 B per secondary ray (primary rays
+    are regenerated), TriangleCold 64 B + two edges 32 B + the instance's two matrices 128 B per triangle hit, Material 56 B per shaded hit,
+    16 B per texel fetched, 12 B per sky lookup.  Writes: node record 32 B per ray + 32 B per hit, 48 B per shadow ray (origin + distance,
+    direction, unshadowed contribution), 80 B per spawned ray."""
+    rays = work["closest_rays"]; secondary = rays - stats["primary"]
+    reads = 20 * rays + 80 * secondary + (64 + 32 + 128) * work["triangle_hits"] + 56 * work["shaded_hits"] + 16 * work["texel_fetches"] + 12 * work["sky_lookups"]
+    writes = 32 * rays + 32 * work["shaded_hits"] + 48 * stats["shadow"] + 80 * work["rays_spawned"]
+    return reads + writes
+
+
+def resolve_bytes(work, stats):
+    """k_resolve: node record 32 B per ray + 32 B per hit read, occlusion flag 4 B + contribution 16 B per shadow ray, a child's colour 16 B read and
+    written per spawned ray, 16 B of framebuffer (fp32 RGB + packed) written per primary ray."""
+    return 32 * work["closest_rays"] + 32 * work["shaded_hits"] + 20 * stats["shadow"] + 32 * work["rays_spawned"] + 16 * stats["primary"]
+
+
+def sources_sha16():
+    """Fingerprint of the kernel sources: profiles/*_hbm_traffic.json carries the one it was measured on (tools/hbm_traffic.sh)."""
+    import hashlib, glob
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "cpu-raytracer_amd", "csrc", "*.h")) + glob.glob(os.path.join(REPO, "cpu-raytracer_amd", "csrc", "*.hip"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_roofline(args, sc, work, stats, level0_rays, kern, alone, ms_per_step, tot):
+    """ONE statement of where the frame stands against the chip:
+      headline   whole-frame traversal arithmetic (the reference's own AABB::intersect + triangle-test calls for this frame's rays, triangle tests
+                 priced in box tests) / ms_per_step of the timed region / the chip's rate for that arithmetic alone (experiments/slab_rate, run here);
+      kernel     the kernel with the most GPU time per step in the timed region (HIP events on its launch stream) is named as dominant;
+      per_kernel every frame kernel against ITS bound on ONE denominator: its launches' time per frame with nothing else on the chip
+                 (the serial-mode pass after the timed region) — traversal kernels against the VALU ceiling (closest hit also against the
+                 divergent-gather ceiling), k_shade / k_resolve against HBM bandwidth;
+      traffic    PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) per frame from the newest profiles/r*_hbm_traffic.json, with whether it was measured on
+                 the kernel sources being run; hbm = the algorithmic-bytes view of SURVEY.md 8(d), which does not bind this design."""
+    import glob
+    peak = None if args.no_extras else roofline_peak()
+    name_of = {"k_trace_closest_shade": "k_trace_closest"}
+    per_step = {}
+    for k, v in kern.items():
+        per_step[name_of.get(k, k)] = per_step.get(name_of.get(k, k), 0.0) + v["total_ms_per_step"]
+    dominant = max(per_step, key=per_step.get) if per_step else None
+    traffic = traffic_src = tj = None
+    tfiles = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
+    if tfiles:
+        try:
+            tj = json.load(open(tfiles[-1])); traffic_src = os.path.relpath(tfiles[-1], REPO)
+        except Exception:
+            tj = None
+    lpf = {k: v["launches_per_frame"] for k, v in kern.items()}
+    def traffic_per_frame(k):
+        if not tj or tj.get(k + "_bytes_per_launch") is None or k not in lpf:
+            return None
+        return int(tj[k + "_bytes_per_launch"] * lpf[k])
+    roof = {"bound": "valu", "kernel": dominant, "achieved": None, "peak": None, "unit": "G AABB::intersect equivalents/s", "frac": None,
+            "traffic": traffic_per_frame(dominant) if dominant else None,
+            "traffic_note": None if not tj else f"PMC bytes per frame of {dominant}'s launches (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included), {traffic_src}",
+            "traffic_measured_on_these_sources": None if not tj else (tj.get("sources_sha16") == sources_sha16()),
+            "gpu_ms_per_step_by_kernel": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+            "definition": "achieved = (AABB::intersect calls + triangle tests x their cost in box tests, closest-hit and shadow rays of one frame, the reference's own counts at "
+                          "SIMD_LANE_SIZE 1) / ms_per_step; peak = the chip's rate for that arithmetic with every operand in registers (experiments/slab_rate, 17 VALU per box test); "
+                          "kernel = most GPU time per step in the timed region; per_kernel fractions use each kernel's time per frame ALONE on the chip"}
+    if not peak:
+        return roof
+    slab_peak, tri_peak, peak_src = peak
+    tri_cost = slab_peak / tri_peak
+    units = {"k_trace_closest": slab_equivalents(work, "closest", tri_cost), "k_trace_any": slab_equivalents(work, "any", tri_cost)}
+    frame_units = units["k_trace_closest"] + units["k_trace_any"]
+    ach = frame_units / (ms_per_step * 1e-3) * 1e-9
+    roof.update({"achieved": round(ach, 2), "peak": round(slab_peak, 1), "frac": round(ach / slab_peak, 4), "units_per_frame": int(frame_units),
+                 "triangle_test_cost_in_box_tests": round(tri_cost, 3), "peak_source": peak_src})
+    pk = {}
+    if alone:
+        any_ms = alone.get("k_trace_any", 0.0) + alone.get("k_trace_items", 0.0)
+        if alone.get("k_trace_closest"):
+            t = alone["k_trace_closest"] * 1e-3
+            pk["k_trace_closest"] = {"bound": "valu", "ms_per_frame_alone": round(alone["k_trace_closest"], 4), "units_per_frame": int(units["k_trace_closest"]),
+                                     "frac": round(units["k_trace_closest"] / t * 1e-9 / slab_peak, 4)}
+            gfiles = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_gather_occupancy.txt")))
+            ceil = None
+            if gfiles:
+                for line in open(gfiles[-1]):
+                    f = line.split()
+                    if len(f) > 8 and f[0] == "table" and f[1] == "32" and f[4].rstrip(":") == "4":
+                        ceil = float(f[7])
+            if ceil:       # the per-lane walk's other bound: divergent 64-byte gathers through the vector memory path (experiments/gather_occupancy)
+                recs = work["blas_nodes_closest"] / 2 + work["tri_tests_closest"] + work["instances_closest"]
+                pk["k_trace_closest"]["gather"] = {"bound": "divergent 64-byte gathers", "records_per_frame": int(recs), "G_records_per_s": round(recs / t * 1e-9, 1),
+                                                   "ceiling_G_records_per_s": ceil, "frac": round(recs / t * 1e-9 / ceil, 3), "ceiling_source": os.path.relpath(gfiles[-1], REPO)}
+        if any_ms:
+            pk["k_trace_any"] = {"bound": "valu", "includes": "k_trace_items (the launch that walks the items the packet launch hands over)", "ms_per_frame_alone": round(any_ms, 4),
+                                 "units_per_frame": int(units["k_trace_any"]), "frac": round(units["k_trace_any"] / (any_ms * 1e-3) * 1e-9 / slab_peak, 4)}
+        for k, nbytes in (("k_shade", shade_bytes(work, stats, sc.point_lights.size + sc.spot_lights.size + sc.dir_lights.size)), ("k_resolve", resolve_bytes(work, stats))):
+            if alone.get(k):
+                tr = traffic_per_frame(k)
+                pk[k] = {"bound": "hbm", "ms_per_frame_alone": round(alone[k], 4), "algorithmic_bytes_per_frame": int(nbytes),
+                         "achieved_GBps": round(nbytes / (alone[k] * 1e-3) / 1e9, 1), "peak_GBps": 8000.0, "frac": round(nbytes / (alone[k] * 1e-3) / 8e12, 4),
+                         "traffic_bytes_per_frame": tr, "traffic_over_algorithmic": None if not tr else round(tr / nbytes, 2)}
+        for k in pk:
+            if k in per_step:
+                pk[k]["gpu_ms_per_step_in_timed_region"] = round(per_step[k] + (per_step.get("k_trace_items", 0.0) if k == "k_trace_any" else 0.0), 4)
+    roof["per_kernel"] = pk
+    alg_bytes = algorithmic_bytes_closest(work, level0_rays) + algorithmic_bytes_any(work)
+    frame_traffic = None if not tj else sum(t for t in (traffic_per_frame(k) for k in lpf) if t)
+    roof["hbm"] = {"binding": False, "algorithmic_bytes_per_frame_traversal": int(alg_bytes), "algorithmic_GBps_at_ms_per_step": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                   "peak_GBps": 8000.0, "traffic_bytes_per_frame_all_kernels": frame_traffic,
+                   "traffic_frac_of_peak": None if not frame_traffic else round(frame_traffic / (ms_per_step * 1e-3) / 8e12, 4),
+                   "note": "SURVEY 8(d)'s byte model (reference struct sizes x nodes / triangles visited) exceeds the HBM peak at this frame rate without any work being "
+                           "skipped: a packet fetches a node once for 64 rays and the 31 MB scene is cache-resident, so the measured traffic is a small fraction of it"}
+    return roof
+
+
+
 def launch_plan(n_gpus, argv, master_port=None, env=None):
     """`python bench.py --gpus N` without a launcher around it: the ranks this process will start, one fresh process per GPU (what
     `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` would start: same environment variables, rank r on device r).
@@ -393,101 +508,10 @@ def main():
 
     if rank == 0:
         mrays = tot[4] / (ms_per_step * 1e-3) * 1e-6
-        by_kernel = {}
-        for name, ms in ktimes:
-            by_kernel.setdefault(name, []).append(ms)
-        kern = {k: {"launches": len(v), "avg_ms": float(np.mean(v)), "total_ms_per_step": float(np.sum(v)) / max(args.steps, 1)} for k, v in by_kernel.items()}
-        # the shadow rays of a frame are traced by the packet launch AND the launch that walks the items it hands over (split walk): for
-        # the roofline the two are one unit of work, so the item launches' time is added to the packet launches' (per launch of the latter)
-        def with_items(times):
-            g = _group(times)
-            if g.get("k_trace_any") and g.get("k_trace_items"):
-                return float(np.mean(g["k_trace_any"])) + float(np.sum(g["k_trace_items"])) / len(g["k_trace_any"])
-            return float(np.mean(g["k_trace_any"])) if g.get("k_trace_any") else None
-        if "k_trace_any" in kern and "k_trace_items" in kern:
-            kern["k_trace_any"]["avg_ms_packet_launch_only"] = kern["k_trace_any"]["avg_ms"]
-            kern["k_trace_any"]["avg_ms"] = with_items(ktimes)
-        levels = int(sc.config["bounces"][0]) + 1
-        alg = {"k_trace_closest": (algorithmic_bytes_closest(work, level0_rays), work["closest_rays"]),
-               "k_trace_any": (algorithmic_bytes_any(work), work["any_rays"])}
-        for k, (b, n) in alg.items():
-            if k in kern:
-                lpf = kern[k]["launches"] / max(args.steps, 1)          # launches per frame (closest: one per level; any: level 0 + levels 1..D)
-                kern[k]["launches_per_frame"] = lpf
-                kern[k]["algorithmic_GBps"] = round((b / lpf) / (kern[k]["avg_ms"] * 1e-3) / 1e9, 2)
-                kern[k]["Grays_per_s"] = round((n / lpf) / (kern[k]["avg_ms"] * 1e-3) / 1e9, 4)
-                kern[k]["bytes_per_ray"] = round(b / max(n, 1), 1)
-        # ---- roofline of the dominant kernel: the traversal kernel whose launches are the longest (the ONE shadow-ray launch of a frame:
-        # 74 % of the rays; the four closest-hit launches are reported next to it in `roofline.other`) ----
-        # What binds these kernels is the CU's instruction issue (VALU + SALU) on branchy fp32 box / triangle tests, not HBM: the 31 MB
-        # scene is cache-resident, measured memory traffic is a few per cent of the algorithmic bytes.  So the roofline
-        # is a compute one, in units of the algorithm itself: achieved = the reference's AABB::intersect + triangle test calls of the
-        # kernel's rays (triangle tests priced in box tests) / launch time; peak = the chip's rate for that arithmetic with every
-        # operand in registers (experiments/slab_rate.hip).  frac <= 1 by construction.  The HBM view is reported next to it.
-        dom = max((k for k in alg if k in kern), key=lambda k: kern[k]["avg_ms"], default="k_trace_any")
-        bytes_frame = alg[dom][0]
-        launches_per_frame = kern[dom]["launches_per_frame"] if dom in kern else levels
-        avg_s = kern[dom]["avg_ms"] * 1e-3 if dom in kern else float("nan")
-        achieved_gbps = (bytes_frame / launches_per_frame) / avg_s / 1e9 if dom in kern else None
-        traffic = traffic_src = None
-        import glob
-        tfiles = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
-        if tfiles:
-            try:
-                tj = json.load(open(tfiles[-1]))
-                traffic = tj.get(dom + "_bytes_per_launch"); traffic_src = os.path.relpath(tfiles[-1], REPO)
-                if dom == "k_trace_any" and traffic is not None and tj.get("k_trace_items_bytes_per_launch"): traffic += tj["k_trace_items_bytes_per_launch"]
-            except Exception:
-                traffic = None
-        peak = None if args.no_extras else roofline_peak()
-        roof = {"bound": "valu", "kernel": dom, "achieved": None, "peak": None, "unit": "G AABB::intersect equivalents/s", "frac": None, "traffic": traffic}
-        if dom == "k_trace_any" and "k_trace_items" in kern:
-            roof["includes"] = "k_trace_items (the launch that walks the items the shadow-ray packet launch hands over: its time and traffic are added per packet launch)"
-        if peak and dom in kern:
-            slab_peak, tri_peak, peak_src = peak
-            tri_cost = slab_peak / tri_peak
-            kind = "closest" if dom == "k_trace_closest" else "any"
-            units_launch = slab_equivalents(work, kind, tri_cost) / launches_per_frame
-            ach = units_launch / avg_s * 1e-9
-            roof.update({"achieved": round(ach, 2), "peak": round(slab_peak, 1), "frac": round(ach / slab_peak, 4),
-                         "units_per_launch": int(units_launch), "avg_launch_ms": round(kern[dom]["avg_ms"], 5),
-                         "triangle_test_cost_in_box_tests": round(tri_cost, 3), "peak_source": peak_src})
-            if serial_times:
-                st = _group(serial_times).get(dom)
-                if st:
-                    st_ms = with_items(serial_times) if dom == "k_trace_any" else float(np.mean(st))
-                    roof["frac_one_frame_at_a_time"] = round(units_launch / (st_ms * 1e-3) * 1e-9 / slab_peak, 4)
-            roof["other"] = {}
-            for k in alg:
-                if k in kern and k != dom:
-                    kd = "closest" if k == "k_trace_closest" else "any"
-                    u = slab_equivalents(work, kd, tri_cost) / kern[k]["launches_per_frame"]
-                    roof["other"][k] = {"units_per_launch": int(u), "avg_launch_ms": round(kern[k]["avg_ms"], 5), "frac": round(u / (kern[k]["avg_ms"] * 1e-3) * 1e-9 / slab_peak, 4)}
-                    if serial_times and _group(serial_times).get(k):
-                        k_ms = with_items(serial_times) if k == "k_trace_any" else float(np.mean(_group(serial_times)[k]))
-                        roof["other"][k]["frac_one_frame_at_a_time"] = round(u / (k_ms * 1e-3) * 1e-9 / slab_peak, 4)
-        # the closest-hit launches walk per lane: what binds them is the rate at which the vector memory path serves divergent 64-byte
-        # records (experiments/gather_occupancy.hip), so they get that view too: records = child pairs fetched (half the nodes tested)
-        # + triangles tested + instances entered, per frame, over the closest-hit time of one frame rendered alone
-        gfiles = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_gather_occupancy.txt")))
-        if gfiles and serial_times and _group(serial_times).get("k_trace_closest") and roof.get("other", {}).get("k_trace_closest") is not None:
-            ceil = None
-            for line in open(gfiles[-1]):
-                f = line.split()
-                if len(f) > 8 and f[0] == "table" and f[1] == "32" and f[4].rstrip(":") == "4":
-                    ceil = float(f[7])
-            recs = work["blas_nodes_closest"] / 2 + work["tri_tests_closest"] + work["instances_closest"]
-            t = float(np.sum(_group(serial_times)["k_trace_closest"])) / max(len(_group(serial_times)["k_trace_closest"]) / levels, 1) * 1e-3
-            if ceil:
-                roof["other"]["k_trace_closest"]["gather"] = {"bound": "divergent 64-byte gathers (vector memory path)", "records_per_frame": int(recs),
-                                                              "G_records_per_s": round(recs / t * 1e-9, 1), "ceiling_G_records_per_s": ceil,
-                                                              "frac": round(recs / t * 1e-9 / ceil, 3), "ceiling_source": os.path.relpath(gfiles[-1], REPO)}
-        roof["hbm"] = {"algorithmic_bytes_per_launch": int(bytes_frame / max(launches_per_frame, 1)),
-                       "algorithmic_GBps": None if achieved_gbps is None else round(achieved_gbps, 1), "peak_GBps": 8000.0,
-                       "traffic_bytes_per_launch": traffic, "traffic_source": traffic_src,
-                       "traffic_frac_of_peak": None if (traffic is None or dom not in kern) else round(traffic / avg_s / 8e12, 4),
-                       "note": "algorithmic bytes = reference struct sizes x nodes / triangles visited (SURVEY 8d); the scene is cache-resident, so the "
-                               "PMC traffic (FETCH_SIZE x 2 + WRITE_SIZE, tools/hbm_traffic.sh) is a small fraction of it and HBM does not bind"}
+        steps = max(args.steps, 1)
+        kern = {k: {"launches_per_frame": len(v) / steps, "avg_ms": float(np.mean(v)), "total_ms_per_step": float(np.sum(v)) / steps} for k, v in _group(ktimes).items()}
+        alone = None if not serial_times else {k: float(np.sum(v)) / min(args.steps, 10) for k, v in _group(serial_times).items()}      # ms per frame, this kernel alone on the chip
+        roof = build_roofline(args, sc, work, stats, level0_rays, kern, alone, ms_per_step, tot)
         out = {
             "metric": "Mrays/s (primary+shadow+reflection+refraction)", "value": round(mrays, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),

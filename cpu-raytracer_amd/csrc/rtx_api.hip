@@ -318,12 +318,14 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->q.pk_defer_t0 = (int)knob_int("RTX_PK_DEFER", 8, 0, 64);
     c->q.pk_defer_leaf = (int)knob_int("RTX_PK_DEFER_LEAF", c->q.pk_defer_t0 / 2, 0, 64);
     c->q.pk_defer_t0_closest = (int)knob_int("RTX_PK_DEFER_CLOSEST", 64, 0, 64);
+    c->q.pk_closest_asm = (int)knob_int("RTX_PK_CLOSEST_ASM", 1, 0, 1);
+    c->q.pk_defer_t0_primary = (int)knob_int("RTX_PK_DEFER_PRIMARY", c->q.pk_closest_asm ? 4 : 64, 0, 64);
     c->q.pk_order = (int)knob_int("RTX_PK_ORDER", 1, 0, 1);
     c->q.prof_level = (int)knob_int("RTX_LANE_PROF_LEVEL", 2, 0, RTX_MAX_LEVELS);      // -DRTX_LANE_PROF builds only (tools/lane_prof.py)
     c->q.pk_defer_grow = (int)knob_int("RTX_PK_GROW", 3, 0, 31);
     c->q.spill_threads = (int)max_threads;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast
-    if (!rc) rc = ensure(c, c->d_pk_fifo, (size_t)c->q.spill_threads * RTX_PK_FIFO * 4);
+    if (!rc) rc = ensure(c, c->d_pk_fifo, (size_t)c->q.spill_threads * RTX_PK_FIFO * 8);        // (reference, key) per work-list entry
     { int ib = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&ib, k_items, RTX_ITEM_BLOCK, 0); c->item_blocks = c->n_cu * (ib > 0 ? ib : 4);
       const double f = knob_real("RTX_ITEM_GRID", 0.0, 0.05, 64.0); if (f > 0.0) c->item_blocks = (int)(c->n_cu * f) > 0 ? (int)(c->n_cu * f) : 1; }
     c->q.pk_items = nullptr; c->q.pk_item_count = nullptr; c->q.pk_item_cap = 0;      // sized per render call (render_tiles_impl)
@@ -749,7 +751,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
     for (int done = 0; done < tile_count; done += batch_tiles) {
         const int n = (tile_count - done) < batch_tiles ? (tile_count - done) : batch_tiles;
         DevQueues q = c->q;
-        if (pk_closest) q.pk_defer_t0_closest = q.pk_defer_t0;
+        if (pk_closest) q.pk_defer_t0_closest = q.pk_defer_t0_primary = q.pk_defer_t0;
         q.first_tile = first_tile + done * tile_stride; q.tile_stride = tile_stride; q.tile_count = n; q.primary_slots = n * 1024;
         q.tm_packed = tile_major; q.tm_base = done * 1024;
         q.stats_partial = (uint32_t *)c->d_stats_partial.p; q.stats_stride = stats_stride;
@@ -1388,7 +1390,7 @@ extern "C" int rtx_debug_trace_rays(rtx_ctx * c, const float * rays18, int32_t n
     hipLaunchKernelGGL(k_debug_fill_rays, dim3((n + 255) / 256), dim3(256), 0, c->stream, q, din, n);
     if (flags & RTX_RENDER_LANE_TRACE) hipLaunchKernelGGL((k_trace_fast<false>), dim3(c->trace_blocks_closest), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, 1, 1);
     else {
-        if (flags & RTX_RENDER_PACKET_CLOSEST) q.pk_defer_t0_closest = q.pk_defer_t0;
+        if (flags & RTX_RENDER_PACKET_CLOSEST) q.pk_defer_t0_closest = q.pk_defer_t0_primary = q.pk_defer_t0;
         hipLaunchKernelGGL((k_packet<false, false>), dim3(c->pk_blocks_closest), dim3(RTX_PK_BLOCK), 0, c->stream, sc, q, 1, 1);
     }
     hipLaunchKernelGGL(k_debug_rebuild, dim3((n + 255) / 256), dim3(256), 0, c->stream, sc, q, din, dout, n);

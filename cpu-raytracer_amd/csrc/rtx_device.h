@@ -140,10 +140,12 @@ struct DevQueues {
 
     int32_t *     spill;          // traversal stack spill, 3 regions of [(entry - RTX_LDS_STACK) * spill_threads + thread]: closest entries, closest keys, shadow entries
     int32_t       spill_threads;
-    int32_t *     pk_fifo;        // closest-hit hybrid walk: per-lane work lists, [RTX_PK_FIFO entries][spill_threads] (rtx_packet.h)
+    int32_t *     pk_fifo;        // closest-hit hybrid walk: per-lane work lists of (reference, key) pairs, [RTX_PK_FIFO entries][spill_threads] (rtx_packet.h)
     int32_t       prof_level;     // RTX_LANE_PROF builds: the level whose closest-hit launch leaves its phase profile in the work counters
     int32_t       pk_order;       // shadow-ray packets: 1 = last level first (default), 0 = queue order
     int32_t       pk_defer_grow;  // ... threshold = pk_defer_t0 + (steps of this packet walk >> pk_defer_grow)
+    int32_t       pk_closest_asm; // 1: the shared part of a closest-hit BLAS walk runs in pk_blas_closest_asm (hand-scheduled), 0: compiled walk (A/B)
+    int32_t       pk_defer_t0_primary;   // the closest-hit threshold of level 0: the 8x8-pixel packets of primary rays share the top of their walk (pk_blas_closest_asm)
     int32_t       pk_defer_t0_closest;   // the same threshold for closest-hit packets (64 = every lane walks its ray privately from the BLAS root)
     int32_t       pk_defer_t0;    // hybrid any-hit walk: nodes wanted by at most this many lanes (+ walk length / 8) go to the lanes' private stacks
     int32_t       pk_defer_leaf;  // the same for leaves (a leaf costs the packet one triangle test per triangle)

@@ -903,7 +903,7 @@ RTX_D void pk_blas_any_asm4(PkWalk & W, rtx_cptr nodes4, const uint32_t lane_lds
     if (err) W.err = 1;
 }
 
-struct PkHybrid { int * stk; float * stk_key; uint32_t lane_lds; int * spill; float * spill_key; int spill_stride; int * fifo; int fifo_stride; int t0, t_leaf, grow; uint32_t item_cap; unsigned long long item_base; };
+struct PkHybrid { int * stk; float * stk_key; uint32_t lane_lds; int * spill; float * spill_key; int spill_stride; int2 * fifo; int fifo_stride; int t0, t_leaf, grow; uint32_t item_cap; unsigned long long item_base; uint32_t gthread; int closest_asm; };
 
 // ---- hybrid any-hit walk, per-lane phase -----------------------------------------------------------------------------------------
 // Walks the subtrees the packet walk handed to the lanes' private stacks (entries are nodes that already passed the lane's slab test,
@@ -1060,10 +1060,17 @@ RTX_D void pk_lane_phase_any4(PkWalk & W, const int lane, const uint32_t lane_ld
 // that point on: the far child re-tested at pop time against the then-current closest distance (entries not tested yet: the same test
 // on the node's own box), the lane's own near / far order, strict comparisons.  Results are those of the reference's per-ray loop.
 #define RTX_PK_FIFO 48                      // work-list entries per lane (HBM, [entry][thread]); a lane turns private only if the list cannot overflow
-#define PK_FIFO_PRETESTED 0x40000000
+// A work-list entry is (reference, key).  reference: 0x40000000 | axis << 28 | leaf count << 24 | first (the node's own (first, count): nothing to
+// fetch before its children / triangles; nodes with first >= 2^24 or 16+ triangles: the node index, fetched when its turn comes).  key: the
+// lane's t_near of the node's box, computed by the shared walk when it popped the entry — the reference's pop-time test at the entry's turn is
+// exactly `key < closest distance then` (slab_test_key); -inf for a node the lane has passed already (hand-over, parked sign split); NaN =
+// "test the fetched box" (entries written by the compiled walk, which has no per-lane t_near at hand).
+#define PK_FIFO_PACKED 0x40000000
+#define PK_KEY_PASSED (-INFINITY)
 RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered, const PkHybrid & H, rtx_gptr nodes, rtx_gptr tris) {
     const int fifo_n = W.fifo_n;
     int fi = 0, sp = 0;
+    int2 nxt = fifo_n > 0 ? H.fifo[0] : make_int2(0, 0);          // the next work-list entry is always in flight before it is needed
     const v3 co = V3(W.ray.o_xy.x, W.ray.o_xy.y, W.ray.o_zz.x), cd = W.ray.d, cinv = V3(W.ray.i_xy.x, W.ray.i_xy.y, W.ray.i_zz.x);
     float tcur = W.ray.tcur;
     bool have_cur = false; int cur_first = 0, cur_cnt = 0;
@@ -1168,11 +1175,17 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
                     have_cur = true;
                 }
             } else if (fi < fifo_n) {
-                const int e = H.fifo[fi * H.fifo_stride]; fi++;
-                const int idx = e & 0x3fffffff;
-                const float4 na = gld(nodes, 2 * idx), nb = gld(nodes, 2 * idx + 1);
-                float k;
-                if ((e & PK_FIFO_PRETESTED) || slab_test_sel<true>(na, nb, co, cinv, tcur, k)) { cur_first = as_i(na.w); cur_cnt = as_i(nb.w); have_cur = true; }
+                const int e = nxt.x; const float key = as_f(nxt.y);
+                fi++;
+                if (fi < fifo_n) nxt = H.fifo[fi * H.fifo_stride];
+                if (e & PK_FIFO_PACKED) {
+                    if (key < tcur) { cur_first = e & 0x00ffffff; cur_cnt = (int)((((uint32_t)e >> 28) & 3u) << 30) | ((e >> 24) & 15); have_cur = true; }
+                } else {
+                    const float4 na = gld(nodes, 2 * e), nb = gld(nodes, 2 * e + 1);
+                    float k;
+                    const bool pass = (key != key) ? slab_test_sel<true>(na, nb, co, cinv, tcur, k) : (key < tcur);
+                    if (pass) { cur_first = as_i(na.w); cur_cnt = as_i(nb.w); have_cur = true; }
+                }
             }
         }
 #ifdef RTX_LANE_PROF
@@ -1191,6 +1204,335 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
     W.fifo_n = 0;
 }
 
+// ---- the whole closest-hit walk of one BLAS for the lanes that walk TOGETHER, hand-scheduled -------------------------------------------
+// BottomLevelBVH::trace (BottomLevelBVH.cpp:355-396) for the lanes of W.m from the node in W.cur_*, until the packet stack is back at
+// W.floor_sp: ordered descend with sign split (the asm of pk_descend), leaves (triangle_trace's hit test with the triangle in SGPRs,
+// every lane against its OWN closest distance, updated under the hit mask), pops with the reference's pop-time re-test of a far child
+// (its own box fetched through the scalar cache, 32 bytes), and the hybrid hand-over: a node wanted by few lanes, and every later
+// stack entry carrying a private lane's bit, goes to those lanes' work lists (HBM, [entry][thread]) for pk_lane_phase_closest.
+// Exactness is the argument at the top of this file: every lane meets the nodes the reference pops and passes for it, in its own
+// near / far order (a far child is pushed with the lanes that pass NOW and re-tested at pop time against their distances THEN).
+//   stack entry: a = first, b = count | axis << 30, mask, idx = node index, df = depth | PK_FLAG_PRETESTED
+//   SGPRs: s[64:79] child pair / triangle / popped node, s[80:93] temporaries, s[94:97] bases, s98 / s99 triangle loop; VGPRs v[24:31] + operands.
+#define PK_ASM_REF /* s79 = work-list reference of the node in (first, cnt, idx): its packed (first, count) or, where that does not fit, its index */ \
+        "s_and_b32 s76, %[cnt], 0x3fffffff\n\t"                                                                                     \
+        "s_cmp_lt_u32 s76, 16\n\t"                                                                                                  \
+        "s_cselect_b32 s77, 1, 0\n\t"                                                                                               \
+        "s_cmp_lt_u32 %[first], 0x1000000\n\t"                                                                                      \
+        "s_cselect_b32 s78, 1, 0\n\t"                                                                                               \
+        "s_and_b32 s77, s77, s78\n\t"                                                                                               \
+        "s_lshr_b32 s78, %[cnt], 30\n\t"                                                                                            \
+        "s_lshl_b32 s78, s78, 28\n\t"                                                                                               \
+        "s_lshl_b32 s76, s76, 24\n\t"                                                                                               \
+        "s_or_b32 s78, s78, s76\n\t"                                                                                                \
+        "s_or_b32 s78, s78, %[first]\n\t"                                                                                           \
+        "s_or_b32 s78, s78, 0x40000000\n\t"                                                                                         \
+        "s_cmp_lg_u32 s77, 0\n\t"                                                                                                   \
+        "s_cselect_b32 s79, s78, %[idx]\n\t"
+#define PK_ASM_FIFO_APPEND(MASK_LO, MASK_HI, KEY) /* (s79, KEY) to the work lists of the lanes of the mask */                        \
+        "s_mov_b64 s[92:93], exec\n\t"                                                                                              \
+        "s_mov_b32 exec_lo, " MASK_LO "\n\t"                                                                                        \
+        "s_mov_b32 exec_hi, " MASK_HI "\n\t"                                                                                        \
+        "v_mov_b32 v28, s79\n\t"                                                                                                    \
+        "v_mov_b32 v29, " KEY "\n\t"                                                                                                \
+        "global_store_dwordx2 %[fvoff], v[28:29], %[fbase]\n\t"                                                                     \
+        "v_add_u32 %[fvoff], %[fstride], %[fvoff]\n\t"                                                                              \
+        "v_add_u32 %[fn], 1, %[fn]\n\t"                                                                                             \
+        "s_mov_b64 exec, s[92:93]\n\t"
+RTX_D void pk_blas_closest_asm(PkWalk & W, const int stack_size, const int ordered, const PkHybrid & H, const int prim, const uint32_t gthread) {
+    W.cur_first = rfl(W.cur_first); W.cur_cnt = rfl(W.cur_cnt); W.cur_idx = rfl(W.cur_idx); W.m = rfl64(W.m); W.sp = rfl(W.sp);
+    W.depth = rfl(W.depth); W.pub = rfl64(W.pub);
+    int err = 0, steps = rfl(W.pk_steps);
+    const int floor_sp = rfl(W.floor_sp), ssz = rfl(stack_size), ord = rfl(ordered), t0d = rfl(H.t0), gsh = rfl(H.grow), primv = rfl(prim);
+    const unsigned long long posx = __ballot(W.ray.d.x > 0.0f), posy = __ballot(W.ray.d.y > 0.0f), posz = __ballot(W.ray.d.z > 0.0f);
+    const float eps = RAY_EPSILON;
+    const unsigned long long nodes = rfl64((unsigned long long)W.nodes), tris = rfl64((unsigned long long)W.tris);
+    const unsigned long long fbase = rfl64((unsigned long long)(H.fifo - gthread));          // H.fifo = work lists + this thread's index
+    const int fstride = rfl(H.fifo_stride * 8);
+    uint32_t fvoff = (gthread + (uint32_t)W.fifo_n * (uint32_t)H.fifo_stride) * 8u;           // byte offset of this lane's next work-list entry
+    float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
+    asm volatile(
+        "s_mov_b64 s[94:95], %[nodes]\n\t"
+        "s_mov_b64 s[96:97], %[tris]\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 PKC_POP_%=\n\t"
+        "PKC_DISPATCH_%=:\n\t"
+        // hybrid: a node wanted by few lanes (threshold grows with the length of the walk) is not walked by the packet
+        "s_bcnt1_i32_b64 s89, %[m]\n\t"
+        "s_lshr_b32 s90, %[steps], %[gsh]\n\t"
+        "s_add_i32 s90, s90, %[t0d]\n\t"
+        "s_add_i32 %[steps], %[steps], 1\n\t"
+        "s_cmp_le_u32 s89, s90\n\t"
+        "s_cbranch_scc0 PKC_WALK_%=\n\t"
+        "s_sub_i32 s90, %[sp], %[floor]\n\t"                 // the lanes' work lists must be able to take every entry still on the stack
+        "s_add_i32 s90, s90, 2\n\t"
+        "s_cmp_le_i32 s90, %[fifomax]\n\t"
+        "s_cbranch_scc0 PKC_WALK_%=\n\t"
+        "s_mov_b64 s[86:87], %[m]\n\t"
+        PK_ASM_REF
+        PK_ASM_FIFO_APPEND("s86", "s87", "0xff800000")        // key -inf: the lanes have just passed this node
+        "s_andn2_b64 %[pub], %[pub], %[m]\n\t"
+        "s_branch PKC_POP_%=\n\t"
+        "PKC_WALK_%=:\n\t"
+        "s_and_b32 s88, %[cnt], 0x3fffffff\n\t"
+        "s_cmp_lg_u32 s88, 0\n\t"
+        "s_cbranch_scc1 PKC_LEAF_%=\n\t"
+        // ---------------- inner node (pk_descend's step) ----------------
+        "s_add_i32 s90, %[depth], 2\n\t"
+        "s_cmp_gt_i32 s90, %[ssz]\n\t"
+        "s_cselect_b32 %[err], 1, %[err]\n\t"
+        "s_lshl_b32 s92, %[first], 5\n\t"
+        "s_load_dwordx16 s[64:79], s[94:95], s92\n\t"
+        // order: every lane must see ITS OWN near / far order; lanes that disagree are parked on this node
+        "s_mov_b32 s91, 1\n\t"
+        "s_cmp_eq_u32 %[ordered], 0\n\t"
+        "s_cbranch_scc1 PKC_ORD_%=\n\t"
+        "s_lshr_b32 s90, %[cnt], 30\n\t"
+        "s_cmp_eq_u32 s90, 0\n\t"
+        "s_cbranch_scc1 PKC_ORD_%=\n\t"
+        "s_mov_b64 s[86:87], %[posx]\n\t"
+        "s_cmp_eq_u32 s90, 2\n\t"
+        "s_cselect_b64 s[86:87], %[posy], s[86:87]\n\t"
+        "s_cmp_eq_u32 s90, 3\n\t"
+        "s_cselect_b64 s[86:87], %[posz], s[86:87]\n\t"
+        "s_and_b64 s[86:87], s[86:87], %[m]\n\t"
+        "s_cmp_eq_u64 s[86:87], 0\n\t"
+        "s_cselect_b32 s91, 0, 1\n\t"
+        "s_cbranch_scc1 PKC_ORD_%=\n\t"
+        "s_cmp_eq_u64 s[86:87], %[m]\n\t"
+        "s_cbranch_scc1 PKC_ORD_%=\n\t"
+        // split: park (node, m & ~pos) as a pretested entry, continue with the left-first lanes
+        "s_andn2_b64 s[88:89], %[m], s[86:87]\n\t"
+        "s_mov_b64 %[m], s[86:87]\n\t"
+        "s_cmp_ge_i32 %[sp], 64\n\t"
+        "s_cselect_b32 %[err], 1, %[err]\n\t"
+        "s_cbranch_scc1 PKC_ORD_%=\n\t"
+        "s_mov_b32 m0, %[sp]\n\t"
+        "s_or_b32 s90, %[depth], 0x20000000\n\t"
+        "v_writelane_b32 %[sta], %[first], m0\n\t"
+        "v_writelane_b32 %[stb], %[cnt], m0\n\t"
+        "v_writelane_b32 %[stmlo], s88, m0\n\t"
+        "v_writelane_b32 %[stmhi], s89, m0\n\t"
+        "v_writelane_b32 %[stdf], s90, m0\n\t"
+        "v_writelane_b32 %[stidx], %[idx], m0\n\t"
+        "s_add_i32 %[sp], %[sp], 1\n\t"
+        "PKC_ORD_%=:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        PK_ASM_SLAB(64, 65, 66, 67, 68, 69, "s[82:83]")
+        PK_ASM_SLAB(72, 73, 74, 75, 76, 77, "s[84:85]")
+        // near / far (left child index = first, right = first + 1)
+        "s_add_i32 s90, %[first], 1\n\t"
+        "s_cmp_lg_u32 s91, 0\n\t"
+        "s_cselect_b64 s[86:87], s[82:83], s[84:85]\n\t"
+        "s_cselect_b64 s[88:89], s[84:85], s[82:83]\n\t"
+        "s_cselect_b32 s80, s70, s78\n\t"
+        "s_cselect_b32 s81, s71, s79\n\t"
+        "s_cselect_b32 s92, s78, s70\n\t"
+        "s_cselect_b32 s93, s79, s71\n\t"
+        "s_cselect_b32 s82, %[first], s90\n\t"          // near index
+        "s_cselect_b32 s83, s90, %[first]\n\t"          // far index
+        "s_cmp_eq_u64 s[86:87], 0\n\t"
+        "s_cbranch_scc1 PKC_NONEAR_%=\n\t"
+        "s_cmp_eq_u64 s[88:89], 0\n\t"
+        "s_cbranch_scc1 PKC_NOFAR_%=\n\t"
+        "s_cmp_ge_i32 %[sp], 64\n\t"
+        "s_cbranch_scc1 PKC_OVER_%=\n\t"
+        "s_mov_b32 m0, %[sp]\n\t"
+        "s_nop 0\n\t"
+        "v_writelane_b32 %[sta], s92, m0\n\t"
+        "v_writelane_b32 %[stb], s93, m0\n\t"
+        "v_writelane_b32 %[stmlo], s88, m0\n\t"
+        "v_writelane_b32 %[stmhi], s89, m0\n\t"
+        "v_writelane_b32 %[stdf], %[depth], m0\n\t"
+        "v_writelane_b32 %[stidx], s83, m0\n\t"
+        "s_add_i32 %[sp], %[sp], 1\n\t"
+        "PKC_NOFAR_%=:\n\t"
+        "s_mov_b32 %[first], s80\n\t"
+        "s_mov_b32 %[cnt], s81\n\t"
+        "s_mov_b32 %[idx], s82\n\t"
+        "s_mov_b64 %[m], s[86:87]\n\t"
+        "s_add_i32 %[depth], %[depth], 1\n\t"
+        "s_branch PKC_DISPATCH_%=\n\t"
+        "PKC_OVER_%=:\n\t"
+        "s_mov_b32 %[err], 1\n\t"
+        "s_branch PKC_NOFAR_%=\n\t"
+        "PKC_NONEAR_%=:\n\t"
+        "s_cmp_eq_u64 s[88:89], 0\n\t"
+        "s_cbranch_scc1 PKC_POP_%=\n\t"
+        "s_mov_b32 %[first], s92\n\t"
+        "s_mov_b32 %[cnt], s93\n\t"
+        "s_mov_b32 %[idx], s83\n\t"
+        "s_mov_b64 %[m], s[88:89]\n\t"
+        "s_branch PKC_DISPATCH_%=\n\t"
+        // ---------------- leaf: triangle_trace's hit test, triangles first .. first + count - 1 (BottomLevelBVH.cpp:214-246) ----------------
+        "PKC_LEAF_%=:\n\t"
+        "s_mov_b32 s98, %[first]\n\t"
+        "s_add_i32 s99, %[first], s88\n\t"
+        "PKC_TRI_%=:\n\t"
+        "s_lshl_b32 s89, s98, 6\n\t"
+        "s_load_dwordx8 s[64:71], s[96:97], s89\n\t"
+        "s_add_u32 s89, s89, 32\n\t"
+        "s_load_dwordx4 s[72:75], s[96:97], s89\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        /* h = cross(d, e2)                                      p0 = s64..66, e1 = s68..70, e2 = s72..74 */
+        "v_mul_f32 %[t0], s74, %[dy]\n\t"
+        "v_mul_f32 %[t1], s73, %[dz]\n\t"
+        "v_mul_f32 %[t2], s72, %[dz]\n\t"
+        "v_mul_f32 %[t3], s74, %[dx]\n\t"
+        "v_mul_f32 %[t4], s73, %[dx]\n\t"
+        "v_mul_f32 %[t5], s72, %[dy]\n\t"
+        "v_sub_f32 v24, %[t0], %[t1]\n\t"
+        "v_sub_f32 v25, %[t2], %[t3]\n\t"
+        "v_sub_f32 v26, %[t4], %[t5]\n\t"
+        /* a = e1.x*h.x + (e1.y*h.y + e1.z*h.z) */
+        "v_mul_f32 %[t0], s69, v25\n\t"
+        "v_mul_f32 %[t1], s70, v26\n\t"
+        "v_mul_f32 %[t2], s68, v24\n\t"
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_add_f32 %[t9], %[t2], %[t0]\n\t"
+        /* f = 1.0f / a, correctly rounded */
+        "v_div_scale_f32 %[t0], s[84:85], %[t9], %[t9], 1.0\n\t"
+        "v_rcp_f32 %[t1], %[t0]\n\t"
+        "v_div_scale_f32 %[t2], vcc, 1.0, %[t9], 1.0\n\t"
+        "v_subrev_f32 v27, s64, %[ox]\n\t"
+        "v_fma_f32 %[t3], -%[t0], %[t1], 1.0\n\t"
+        "v_fmac_f32 %[t1], %[t3], %[t1]\n\t"
+        "v_mul_f32 %[t4], %[t2], %[t1]\n\t"
+        "v_fma_f32 %[t5], -%[t0], %[t4], %[t2]\n\t"
+        "v_fmac_f32 %[t4], %[t5], %[t1]\n\t"
+        "v_fma_f32 %[t0], -%[t0], %[t4], %[t2]\n\t"
+        "v_subrev_f32 v28, s65, %[oy]\n\t"
+        "v_div_fmas_f32 %[t0], %[t0], %[t1], %[t4]\n\t"
+        "v_subrev_f32 v29, s66, %[oz]\n\t"
+        "v_div_fixup_f32 %[t8], %[t0], %[t9], 1.0\n\t"       /* f */
+        /* u = f * (s.x*h.x + (s.y*h.y + s.z*h.z)) */
+        "v_mul_f32 %[t0], v28, v25\n\t"
+        "v_mul_f32 %[t1], v29, v26\n\t"
+        "v_mul_f32 %[t2], v27, v24\n\t"
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_add_f32 %[t0], %[t2], %[t0]\n\t"
+        "v_mul_f32 %[t7], %[t8], %[t0]\n\t"                  /* u */
+        "v_cmp_lt_f32 s[84:85], 0, %[t7]\n\t"
+        "v_cmp_gt_f32 s[86:87], 1.0, %[t7]\n\t"
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
+        "s_and_b64 s[84:85], s[84:85], %[m]\n\t"
+        "s_cmp_lg_u64 s[84:85], 0\n\t"
+        "s_cbranch_scc0 PKC_NEXT_%=\n\t"                     /* no lane of the node passes the u test */
+        /* q = cross(s, e1) */
+        "v_mul_f32 %[t0], s70, v28\n\t"
+        "v_mul_f32 %[t1], s69, v29\n\t"
+        "v_mul_f32 %[t2], s68, v29\n\t"
+        "v_mul_f32 %[t3], s70, v27\n\t"
+        "v_mul_f32 %[t4], s69, v27\n\t"
+        "v_mul_f32 %[t5], s68, v28\n\t"
+        "v_sub_f32 v24, %[t0], %[t1]\n\t"
+        "v_sub_f32 v25, %[t2], %[t3]\n\t"
+        "v_sub_f32 v26, %[t4], %[t5]\n\t"
+        /* v = f * (d.x*q.x + (d.y*q.y + d.z*q.z)) */
+        "v_mul_f32 %[t0], %[dy], v25\n\t"
+        "v_mul_f32 %[t1], %[dz], v26\n\t"
+        "v_mul_f32 %[t2], %[dx], v24\n\t"
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_add_f32 %[t0], %[t2], %[t0]\n\t"
+        "v_mul_f32 %[t6], %[t8], %[t0]\n\t"                  /* v */
+        /* t = f * (e2.x*q.x + (e2.y*q.y + e2.z*q.z)) */
+        "v_mul_f32 %[t0], s73, v25\n\t"
+        "v_mul_f32 %[t1], s74, v26\n\t"
+        "v_mul_f32 %[t2], s72, v24\n\t"
+        "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+        "v_add_f32 %[t0], %[t2], %[t0]\n\t"
+        "v_mul_f32 %[t5], %[t8], %[t0]\n\t"                  /* t */
+        "v_add_f32 %[t4], %[t7], %[t6]\n\t"                  /* u + v */
+        "v_cmp_lt_f32 s[86:87], 0, %[t6]\n\t"
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
+        "v_cmp_gt_f32 s[86:87], 1.0, %[t4]\n\t"
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
+        "v_cmp_lt_f32 s[86:87], %[eps], %[t5]\n\t"
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
+        "v_cmp_lt_f32 s[86:87], %[t5], %[tcur]\n\t"          /* t < this lane's closest distance so far */
+        "s_and_b64 s[84:85], s[84:85], s[86:87]\n\t"
+        "s_cmp_lg_u64 s[84:85], 0\n\t"
+        "s_cbranch_scc0 PKC_NEXT_%=\n\t"
+        /* the lanes that are hit take the triangle (BottomLevelBVH.cpp:248-250; the attributes are rebuilt when the hit is shaded) */
+        "s_mov_b64 s[92:93], exec\n\t"
+        "s_mov_b64 exec, s[84:85]\n\t"
+        "v_mov_b32 %[tcur], %[t5]\n\t"
+        "v_mov_b32 %[bu], %[t7]\n\t"
+        "v_mov_b32 %[bv], %[t6]\n\t"
+        "v_mov_b32 %[btri], s98\n\t"
+        "v_mov_b32 %[bprim], %[prim]\n\t"
+        "s_mov_b64 exec, s[92:93]\n\t"
+        "PKC_NEXT_%=:\n\t"
+        "s_add_i32 s98, s98, 1\n\t"
+        "s_cmp_lt_i32 s98, s99\n\t"
+        "s_cbranch_scc1 PKC_TRI_%=\n\t"
+        // ---------------- pop ----------------
+        "PKC_POP_%=:\n\t"
+        "s_mov_b64 %[m], 0\n\t"
+        "s_cmp_le_i32 %[sp], %[floor]\n\t"
+        "s_cbranch_scc1 PKC_END_%=\n\t"
+        "s_sub_i32 %[sp], %[sp], 1\n\t"
+        "s_mov_b32 m0, %[sp]\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 s84, %[stmlo], m0\n\t"
+        "v_readlane_b32 s85, %[stmhi], m0\n\t"
+        "v_readlane_b32 %[first], %[sta], m0\n\t"
+        "v_readlane_b32 %[cnt], %[stb], m0\n\t"
+        "v_readlane_b32 s91, %[stdf], m0\n\t"
+        "v_readlane_b32 %[idx], %[stidx], m0\n\t"
+        "s_and_b32 %[depth], s91, 0xffff\n\t"
+        "s_bitcmp1_b32 s91, 29\n\t"                           // PK_FLAG_PRETESTED: lanes parked at a sign split have passed this node already
+        "s_cbranch_scc0 PKC_FAR_%=\n\t"
+        // parked split: its private lanes take it as it is (key -inf), its public lanes walk it now
+        "s_andn2_b64 s[86:87], s[84:85], %[pub]\n\t"
+        "s_cmp_lg_u64 s[86:87], 0\n\t"
+        "s_cbranch_scc0 PKC_PRE_PUB_%=\n\t"
+        PK_ASM_REF
+        PK_ASM_FIFO_APPEND("s86", "s87", "0xff800000")
+        "PKC_PRE_PUB_%=:\n\t"
+        "s_and_b64 %[m], s[84:85], %[pub]\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 PKC_POP_%=\n\t"
+        "s_branch PKC_DISPATCH_%=\n\t"
+        // far child: the reference tests it when it pops it, against the closest distance THEN (BottomLevelBVH.cpp:366-370).  Public lanes: now.
+        // Private lanes: at the entry's turn in their own walk — the test is `t_near < distance then` (slab_test_key), so their t_near travels
+        // with the entry as its key; lanes that fail against their distance NOW can only fail later (the distance never grows): dropped here.
+        "PKC_FAR_%=:\n\t"
+        "s_mov_b64 %[m], s[84:85]\n\t"
+        "s_lshl_b32 s88, %[idx], 5\n\t"
+        "s_load_dwordx8 s[64:71], s[94:95], s88\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        PK_ASM_SLAB(64, 65, 66, 67, 68, 69, "s[80:81]")
+        "s_andn2_b64 s[86:87], s[80:81], %[pub]\n\t"
+        "s_cmp_lg_u64 s[86:87], 0\n\t"
+        "s_cbranch_scc0 PKC_FAR_PUB_%=\n\t"
+        PK_ASM_REF
+        PK_ASM_FIFO_APPEND("s86", "s87", "v30")              // v30 = this lane's t_near of the box (PK_ASM_SLAB)
+        "PKC_FAR_PUB_%=:\n\t"
+        "s_and_b64 %[m], s[80:81], %[pub]\n\t"
+        "s_cmp_eq_u64 %[m], 0\n\t"
+        "s_cbranch_scc1 PKC_POP_%=\n\t"
+        "s_branch PKC_DISPATCH_%=\n\t"
+        "PKC_END_%=:\n\t"
+        : [first] "+&s"(W.cur_first), [cnt] "+&s"(W.cur_cnt), [idx] "+&s"(W.cur_idx), [m] "+&s"(W.m), [sp] "+&s"(W.sp), [depth] "+&s"(W.depth),
+          [err] "+&s"(err), [steps] "+&s"(steps), [pub] "+&s"(W.pub),
+          [sta] "+&v"(W.st_a), [stb] "+&v"(W.st_b), [stmlo] "+&v"(W.st_mlo), [stmhi] "+&v"(W.st_mhi), [stdf] "+&v"(W.st_df), [stidx] "+&v"(W.st_idx),
+          [tcur] "+&v"(W.ray.tcur), [bu] "+&v"(W.best_u), [bv] "+&v"(W.best_v), [btri] "+&v"(W.best_tri), [bprim] "+&v"(W.best_prim),
+          [fvoff] "+&v"(fvoff), [fn] "+&v"(W.fifo_n),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7),
+          [t8] "=&v"(t8), [t9] "=&v"(t9)
+        : [nodes] "s"(nodes), [tris] "s"(tris), [floor] "s"(floor_sp), [ssz] "s"(ssz), [eps] "s"(eps), [ordered] "s"(ord), [t0d] "s"(t0d), [gsh] "s"(gsh),
+          [posx] "s"(posx), [posy] "s"(posy), [posz] "s"(posz), [fbase] "s"(fbase), [fstride] "s"(fstride), [prim] "s"(primv), [fifomax] "s"((int)RTX_PK_FIFO),
+          [oxy] "v"(W.ray.o_xy), [ozz] "v"(W.ray.o_zz), [ixy] "v"(W.ray.i_xy), [izz] "v"(W.ray.i_zz),
+          [ox] "v"(W.ray.o_xy.x), [oy] "v"(W.ray.o_xy.y), [oz] "v"(W.ray.o_zz.x), [dx] "v"(W.ray.d.x), [dy] "v"(W.ray.d.y), [dz] "v"(W.ray.d.z)
+        : "vcc", "scc", "m0", "memory",
+          "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",
+          "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
+          "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
+    W.pk_steps = steps;
+    if (err) W.err = 1;
+}
+
 // Walks until the packet is finished (returns true) or, FAST only, until an instance is entered in which some lane's inverse
 // direction is not finite (returns false: the caller continues with the reference-form variant; the state is consistent).
 // `world(o, d)` reloads a lane's world-space ray (kept in memory, not in registers).
@@ -1203,7 +1545,7 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
                 // its lanes turn private and take the node (which they have just passed) as the first entry of their work lists
                 const int thr = H.t0 + (W.pk_steps >> H.grow);
                 if (__popcll(W.m) <= thr && (W.sp - W.floor_sp) + 2 <= RTX_PK_FIFO) {
-                    if ((W.m >> lane) & 1ull) { H.fifo[W.fifo_n * H.fifo_stride] = W.cur_idx | PK_FIFO_PRETESTED; W.fifo_n++; }
+                    if ((W.m >> lane) & 1ull) { H.fifo[W.fifo_n * H.fifo_stride] = make_int2(W.cur_idx, as_i(PK_KEY_PASSED)); W.fifo_n++; }
                     W.pub &= ~W.m; W.m = 0ull;
                     continue;
                 }
@@ -1305,7 +1647,7 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
         if (!ANY && ASM && FAST && (pm & ~W.pub) != 0ull) {
             // private lanes: the entry goes to their work lists (to be re-tested at its turn unless it is a pretested split entry)
             if (((pm & ~W.pub) >> lane) & 1ull) {
-                H.fifo[W.fifo_n * H.fifo_stride] = __builtin_amdgcn_readlane(W.st_idx, W.sp) | ((edf & PK_FLAG_PRETESTED) ? PK_FIFO_PRETESTED : 0); W.fifo_n++;
+                H.fifo[W.fifo_n * H.fifo_stride] = make_int2(__builtin_amdgcn_readlane(W.st_idx, W.sp), (edf & PK_FLAG_PRETESTED) ? as_i(PK_KEY_PASSED) : 0x7fc00000); W.fifo_n++;
             }
             pm &= W.pub;
         }
@@ -1328,6 +1670,19 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
             W.m = (risky ? __ballot(pk_slab<false>(na, nb, W.ray)) : __ballot(pk_slab<FAST>(na, nb, W.ray))) & pm;
             W.cur_idx = 0; W.cur_first = as_i(nb.z); W.cur_cnt = as_i(nb.w);
             if (risky) return false;
+            if (ASM && FAST && !ANY && H.closest_asm) {
+                // the shared part of the closest-hit walk of this instance, hand-scheduled; returns with the packet stack back at floor_sp and
+                // m == 0: the pop below runs the private lanes' phase and returns to world space
+#ifdef RTX_LANE_PROF
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long sw_t0 = __builtin_amdgcn_s_memtime(); const int sw_s0 = W.pk_steps;
+#endif
+                pk_blas_closest_asm(W, sc.stack_size, ordered ? 1 : 0, H, PRIM_TRI | inst, H.gthread);
+#ifdef RTX_LANE_PROF
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                W.lp[13] = (uint32_t)rfl((int)(W.lp[13] + (uint32_t)(__builtin_amdgcn_s_memtime() - sw_t0))); W.lp[14] = (uint32_t)rfl((int)(W.lp[14] + (uint32_t)(W.pk_steps - sw_s0)));
+                W.lp[15] = (uint32_t)rfl((int)(W.lp[15] + 1u));
+#endif
+            }
             if (ASM && FAST && ANY) {
                 // the whole BLAS walk, hand-scheduled (returns with m == 0), then the per-lane phase over what it deferred
                 PK_T0();
@@ -1385,9 +1740,10 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
         const size_t region = (size_t)q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK), gt = blockIdx.x * blockDim.x + threadIdx.x;
         H.spill = q.spill + (ANY ? 2 * region : 0) + gt;
         H.spill_key = (float *)(q.spill + region) + gt;
-        H.fifo = q.pk_fifo + gt; H.fifo_stride = q.spill_threads;
+        H.fifo = (int2 *)q.pk_fifo + gt; H.fifo_stride = q.spill_threads; H.gthread = (uint32_t)gt;
     }
-    H.t0 = ANY ? q.pk_defer_t0 : q.pk_defer_t0_closest; H.t_leaf = q.pk_defer_leaf; H.grow = q.pk_defer_grow;
+    H.closest_asm = q.pk_closest_asm;
+    H.t0 = ANY ? q.pk_defer_t0 : (level == 0 ? q.pk_defer_t0_primary : q.pk_defer_t0_closest); H.t_leaf = q.pk_defer_leaf; H.grow = q.pk_defer_grow;
     H.item_cap = 0; H.item_base = 0ull;
     const uint32_t gwave  = (uint32_t)rfl((int)(blockIdx.x * (RTX_PK_BLOCK / RTX_WAVE) + (threadIdx.x >> 6)));
     const uint32_t nwaves = gridDim.x * (RTX_PK_BLOCK / RTX_WAVE);
@@ -1599,7 +1955,8 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
         atomicAdd(&ctr->work[14], __builtin_amdgcn_s_memtime() - lp_k0);
         atomicAdd(&ctr->work[15], 1ull);                                        // waves
         atomicAdd(&ctr->work[16], __builtin_amdgcn_s_memrealtime() - lp_r0);
-        atomicAdd(&ctr->work[17], (unsigned long long)W.lp[13]); atomicAdd(&ctr->work[18], (unsigned long long)W.lp[14]);      // fused shading: ticks, packets    // the same lifetimes on the constant 100 MHz clock: calibrates the s_memtime tick
+        atomicAdd(&ctr->work[17], (unsigned long long)W.lp[13]); atomicAdd(&ctr->work[18], (unsigned long long)W.lp[14]);      // shared (asm) walks: ticks, node visits (FUSE builds: fused shading ticks, packets)
+        atomicAdd(&ctr->work[19], (unsigned long long)W.lp[15]);                                                                // shared walks    // the same lifetimes on the constant 100 MHz clock: calibrates the s_memtime tick
     }
 #endif
     if (ANY && SPLIT && q.pk_items && lane == 0) { q.pk_item_count[gwave] = (uint32_t)W.item_n; if ((uint32_t)W.item_n > __hip_atomic_load(&ctr->item_max[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ctr->item_max[level], (uint32_t)W.item_n); }      // few waves raise the maximum: one counter sustains only ~90 atomics/us

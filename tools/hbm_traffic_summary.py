@@ -27,6 +27,12 @@ write, nw = collect(sys.argv[2], "WRITE_SIZE")
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 --no-extras` "
                "(3 frames in flight, one stream per frame: 4 closest-hit launches, ONE shadow-ray packet launch + its item launch, 4 shade, 4 resolve per frame), averaged per launch; "
                "bytes = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, both reported in KB; Infinity-Cache hits included (upper bound on HBM traffic)"}
+import hashlib
+_h = hashlib.sha256()
+_csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cpu-raytracer_amd", "csrc")
+for _f in sorted(glob.glob(os.path.join(_csrc, "*.h")) + glob.glob(os.path.join(_csrc, "*.hip"))):
+    _h.update(open(_f, "rb").read())
+out["sources_sha16"] = _h.hexdigest()[:16]        # bench.py compares it with the sources it runs (roofline.traffic_measured_on_these_sources)
 for k in ("k_trace_any", "k_trace_items", "k_trace_closest", "k_shade", "k_resolve"):
     if nf[k] and nw[k]:
         f, w = fetch[k] / nf[k], write[k] / nw[k]

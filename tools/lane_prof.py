@@ -26,5 +26,5 @@ print(f"  iterations with an inner step {raw[2] / it:.2f}, with a leaf {raw[3] /
 print(f"  ticks: child-pair fetch wait {raw[7] / max(raw[0], 1):.2f} of the phase ({raw[7] / max(raw[2], 1) * tick:.3f} us per inner step), "
       f"leaf (fetch + test, serial per triangle) {raw[8] / max(raw[0], 1):.2f} ({raw[8] / max(raw[3], 1) * tick:.3f} us per leaf step), "
       f"pop / work list {raw[9] / max(raw[0], 1):.2f} ({raw[9] / max(raw[4] + raw[5], 1) * tick:.3f} us per pop)")
-if raw[18]:
-    print(f"  fused shading: {raw[18]} packets shaded, {raw[17] / raw[18] * tick:.2f} us per packet (stores drained), {raw[17] / max(raw[14], 1):.2f} of the waves' lifetime")
+if raw[19]:
+    print(f"  shared (asm) walks: {raw[19]}, {raw[18] / raw[19]:.1f} node visits and {raw[17] / raw[19] * tick:.2f} us each ({raw[17] / max(raw[18], 1) * tick:.3f} us per node visit), {raw[17] / max(raw[14], 1):.2f} of the waves' lifetime")
