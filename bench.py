@@ -154,11 +154,11 @@ def reference_cpu_baseline(args, rays_per_frame, stats):
 def shade_bytes(work, stats, lights):
     """Algorithmic bytes of one frame's k_shade launches (DESIGN.md 4): what Raytracer::bounce reads and writes between the trace and the
     recursion, at the sizes of this repo's queue records.  Reads: hit record 20 B per ray, the ray record 80 B per secondary ray (primary rays
-    are regenerated), TriangleCold 64 B + two edges 32 B + the instance's two matrices 128 B per triangle hit, Material 56 B per shaded hit,
+    are regenerated), TriangleCold 64 B + two edges 32 B per triangle hit (the instance's matrices: a handful of lines, L1-resident), Material 56 B per shaded hit,
     16 B per texel fetched, 12 B per sky lookup.  Writes: node record 32 B per ray + 32 B per hit, 48 B per shadow ray (origin + distance,
     direction, unshadowed contribution), 80 B per spawned ray."""
     rays = work["closest_rays"]; secondary = rays - stats["primary"]
-    reads = 20 * rays + 80 * secondary + (64 + 32 + 128) * work["triangle_hits"] + 56 * work["shaded_hits"] + 16 * work["texel_fetches"] + 12 * work["sky_lookups"]
+    reads = 20 * rays + 80 * secondary + (64 + 32) * work["triangle_hits"] + 56 * work["shaded_hits"] + 16 * work["texel_fetches"] + 12 * work["sky_lookups"]
     writes = 32 * rays + 32 * work["shaded_hits"] + 48 * stats["shadow"] + 80 * work["rays_spawned"]
     return reads + writes
 
@@ -250,7 +250,8 @@ def build_roofline(args, sc, work, stats, level0_rays, kern, alone, ms_per_step,
                 tr = traffic_per_frame(k)
                 pk[k] = {"bound": "hbm", "ms_per_frame_alone": round(alone[k], 4), "algorithmic_bytes_per_frame": int(nbytes),
                          "achieved_GBps": round(nbytes / (alone[k] * 1e-3) / 1e9, 1), "peak_GBps": 8000.0, "frac": round(nbytes / (alone[k] * 1e-3) / 8e12, 4),
-                         "traffic_bytes_per_frame": tr, "traffic_over_algorithmic": None if not tr else round(tr / nbytes, 2)}
+                         "traffic_bytes_per_frame": tr, "traffic_over_algorithmic": None if not tr else round(tr / nbytes, 2),
+                         "traffic_frac_of_peak": None if not tr else round(tr / (alone[k] * 1e-3) / 8e12, 4)}
         for k in pk:
             if k in per_step:
                 pk[k]["gpu_ms_per_step_in_timed_region"] = round(per_step[k] + (per_step.get("k_trace_items", 0.0) if k == "k_trace_any" else 0.0), 4)
@@ -405,7 +406,9 @@ def main():
         sl.fb_rgb = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
         sl.fb_packed = torch.zeros(H * W, dtype=torch.int32, device="cuda")
         sl.r.bind_framebuffer(sl.fb_rgb.data_ptr(), sl.fb_packed.data_ptr())
-        sl.stream = torch.cuda.current_stream() if nfl == 1 else torch.cuda.Stream()
+        prio = os.environ.get("RTX_BENCH_STREAM_PRIORITIES", "")          # A/B runs: e.g. "-1,0,0" (torch: -1 = high priority)
+        prio = int(prio.split(",")[k]) if prio and k < len(prio.split(",")) else 0
+        sl.stream = torch.cuda.current_stream() if nfl == 1 else torch.cuda.Stream(priority=prio)
         sl.r.set_stream(sl.stream.cuda_stream)
         sl.gather = None
         if world > 1 or args.force_gather:

@@ -1196,7 +1196,12 @@ extern "C" int rtx_group_attach(rtx_ctx * c, rtx_group * base, rtx_group ** out)
     *out = nullptr;
     hipSetDevice(c->cfg.device);
     GroupHub * h = base->hub;
-    if (!h->xs) HIP_OK(c, hipStreamCreateWithFlags(&h->xs, hipStreamNonBlocking));
+    if (!h->xs) {      // the exchange stream gets the highest priority: RCCL's copy kernel needs a few workgroups' worth of room beside the frames' persistent grids, and should be first in line for it
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (knob_int("RTX_XS_PRIORITY", 1, 0, 1)) HIP_OK(c, hipStreamCreateWithPriority(&h->xs, hipStreamNonBlocking, hi));
+        else HIP_OK(c, hipStreamCreateWithFlags(&h->xs, hipStreamNonBlocking));
+    }
     rtx_group * g = new rtx_group();
     g->ctx = c; g->rank = base->rank; g->world = base->world; g->hub = h; h->refs++;
     const int rc = group_setup(g);
