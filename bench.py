@@ -155,18 +155,20 @@ def shade_bytes(work, stats, lights):
     """Algorithmic bytes of one frame's k_shade launches (DESIGN.md 4): what Raytracer::bounce reads and writes between the trace and the
     recursion, at the sizes of this repo's queue records.  Reads: hit record 20 B per ray, the ray record 80 B per secondary ray (primary rays
     are regenerated), TriangleCold 64 B + two edges 32 B per triangle hit (the instance's matrices: a handful of lines, L1-resident), Material 56 B per shaded hit,
-    16 B per texel fetched, 12 B per sky lookup.  Writes: node record 32 B per ray + 32 B per hit, 48 B per shadow ray (origin + distance,
-    direction, unshadowed contribution), 80 B per spawned ray."""
+    16 B per texel fetched, 12 B per sky lookup.  Writes: node record 32 B per ray + 32 B per hit, point + normal 32 B per lit hit (the shadow rays
+    themselves are derived by their consumers), 80 B per spawned ray."""
     rays = work["closest_rays"]; secondary = rays - stats["primary"]
+    lit_hits = stats["shadow"] // max(lights, 1)
     reads = 20 * rays + 80 * secondary + (64 + 32) * work["triangle_hits"] + 56 * work["shaded_hits"] + 16 * work["texel_fetches"] + 12 * work["sky_lookups"]
-    writes = 32 * rays + 32 * work["shaded_hits"] + 48 * stats["shadow"] + 80 * work["rays_spawned"]
+    writes = 32 * rays + 32 * work["shaded_hits"] + 32 * lit_hits + 80 * work["rays_spawned"]
     return reads + writes
 
 
-def resolve_bytes(work, stats):
-    """k_resolve: node record 32 B per ray + 32 B per hit read, occlusion flag 4 B + contribution 16 B per shadow ray, a child's colour 16 B read and
-    written per spawned ray, 16 B of framebuffer (fp32 RGB + packed) written per primary ray."""
-    return 32 * work["closest_rays"] + 32 * work["shaded_hits"] + 20 * stats["shadow"] + 32 * work["rays_spawned"] + 16 * stats["primary"]
+def resolve_bytes(work, stats, lights):
+    """k_resolve: node record 32 B per ray + 32 B per hit read, point + normal 32 B per lit hit, occlusion flag 4 B per shadow ray, a child's colour
+    16 B read and written per spawned ray, 16 B of framebuffer (fp32 RGB + packed) written per primary ray."""
+    lit_hits = stats["shadow"] // max(lights, 1)
+    return 32 * work["closest_rays"] + 32 * work["shaded_hits"] + 32 * lit_hits + 4 * stats["shadow"] + 32 * work["rays_spawned"] + 16 * stats["primary"]
 
 
 def sources_sha16():
@@ -245,7 +247,8 @@ def build_roofline(args, sc, work, stats, level0_rays, kern, alone, ms_per_step,
         if any_ms:
             pk["k_trace_any"] = {"bound": "valu", "includes": "k_trace_items (the launch that walks the items the packet launch hands over)", "ms_per_frame_alone": round(any_ms, 4),
                                  "units_per_frame": int(units["k_trace_any"]), "frac": round(units["k_trace_any"] / (any_ms * 1e-3) * 1e-9 / slab_peak, 4)}
-        for k, nbytes in (("k_shade", shade_bytes(work, stats, sc.point_lights.size + sc.spot_lights.size + sc.dir_lights.size)), ("k_resolve", resolve_bytes(work, stats))):
+        n_lights = sc.point_lights.size + sc.spot_lights.size + sc.dir_lights.size
+        for k, nbytes in (("k_shade", shade_bytes(work, stats, n_lights)), ("k_resolve", resolve_bytes(work, stats, n_lights))):
             if alone.get(k):
                 tr = traffic_per_frame(k)
                 pk[k] = {"bound": "hbm", "ms_per_frame_alone": round(alone[k], 4), "algorithmic_bytes_per_frame": int(nbytes),

@@ -95,7 +95,7 @@ struct rtx_ctx {
     DevQueues q;
     DevBuf qb[20];
     size_t slots_alloc = 0, shadow_alloc = 0;
-    DevBuf d_stats_partial, d_pk_fifo, d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma, d_pk_heads;
+    DevBuf d_dbg_s0, d_dbg_s1, d_stats_partial, d_pk_fifo, d_counters, d_spill, d_fb_rgb, d_fb_packed, d_display, d_gamma, d_pk_heads;
     int trace_blocks_closest = 0, trace_blocks_any = 0, trace_blocks_count = 0;
     int pk_blocks_closest = 0, pk_blocks_any = 0;    // persistent grids of the packet kernels (even: waves % 8 == 0, see k_begin_batch)
 
@@ -340,7 +340,7 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto & v : c->blas_allocs) for (void * p : v) hipFree(p);
     for (void * p : c->tex_allocs) if (p) hipFree(p);
-    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->d_frame, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads, &c->d_pk_fifo, &c->d_pk_items, &c->d_pk_item_count, &c->d_stats_partial };
+    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->d_frame, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads, &c->d_pk_fifo, &c->d_pk_items, &c->d_pk_item_count, &c->d_stats_partial, &c->d_dbg_s0, &c->d_dbg_s1 };
     for (DevBuf * b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf & b : c->qb) if (b.p) hipFree(b.p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
@@ -612,11 +612,11 @@ static int alloc_queues(rtx_ctx * c, int batch_tiles) {
     int rc = 0, k = 0;
     // rays of level 0 are never stored, but the arrays are indexed by global slot for simplicity of addressing
     void ** f4[] = { (void **)&c->q.r0, (void **)&c->q.r1, (void **)&c->q.r2, (void **)&c->q.r3, (void **)&c->q.r4, (void **)&c->q.h0,
-                     (void **)&c->q.n0, (void **)&c->q.n1, (void **)&c->q.n2, (void **)&c->q.n3, (void **)&c->q.c0, (void **)&c->q.c1 };
+                     (void **)&c->q.n0, (void **)&c->q.n1, (void **)&c->q.n2, (void **)&c->q.n3, (void **)&c->q.c0, (void **)&c->q.c1,
+                     (void **)&c->q.sp, (void **)&c->q.sn };
     for (void ** p : f4) { if (!rc) rc = ensure(c, c->qb[k], slots * 16); *p = c->qb[k].p; k++; }
     if (!rc) rc = ensure(c, c->qb[k], slots * 4); c->q.h1 = (int32_t *)c->qb[k].p; k++;
-    void ** s4[] = { (void **)&c->q.s0, (void **)&c->q.s1, (void **)&c->q.sc };
-    for (void ** p : s4) { if (!rc) rc = ensure(c, c->qb[k], sslots * 16); *p = c->qb[k].p; k++; }
+    c->q.s0 = c->q.s1 = nullptr; c->q.shadow_explicit = 0; c->q.cull = 0;      // explicit shadow rays: rtx_debug_occluded allocates them (debug_explicit_rays)
     if (!rc) rc = ensure(c, c->qb[k], sslots * 4); c->q.socc = (uint32_t *)c->qb[k].p; k++;
     c->q.spill = (int32_t *)c->d_spill.p;
     c->q.counters = (DevCounters *)c->d_counters.p;
@@ -754,6 +754,7 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         if (pk_closest) q.pk_defer_t0_closest = q.pk_defer_t0_primary = q.pk_defer_t0;
         q.first_tile = first_tile + done * tile_stride; q.tile_stride = tile_stride; q.tile_count = n; q.primary_slots = n * 1024;
         q.tm_packed = tile_major; q.tm_base = done * 1024;
+        q.cull = cull ? 1 : 0;
         q.stats_partial = (uint32_t *)c->d_stats_partial.p; q.stats_stride = stats_stride;
         for (int d = 0; d <= RTX_MAX_LEVELS; d++) q.stats_n[d] = 0;
         const DevScene sc = c->scene;
@@ -1414,6 +1415,12 @@ extern "C" int rtx_debug_occluded(rtx_ctx * c, const float * origin_direction_ma
     HIP_OK(c, hipMalloc(&din, (size_t)n * 28));
     HIP_OK(c, hipMemcpy(din, origin_direction_maxdist7, (size_t)n * 28, hipMemcpyHostToDevice));
     DevQueues q = c->q; q.first_tile = 0; q.tile_stride = 1; q.tile_count = (n + 1023) / 1024; q.primary_slots = n; q.tm_packed = nullptr;
+    {   // explicit shadow rays (the frame kernels derive theirs from the hit's point and the light): origin + distance, direction per shadow slot of level 0
+        const size_t sslots = (size_t)q.level_cap[0] * (size_t)(c->scene.light_count > 0 ? c->scene.light_count : 1);
+        rc = ensure(c, c->d_dbg_s0, sslots * 16); if (!rc) rc = ensure(c, c->d_dbg_s1, sslots * 16);
+        if (rc) { hipFree(din); return rc; }
+        q.s0 = (float4 *)c->d_dbg_s0.p; q.s1 = (float4 *)c->d_dbg_s1.p; q.shadow_explicit = 1;
+    }
     const DevScene sc = c->scene;
     hipLaunchKernelGGL(k_debug_fill_shadow, dim3((n + 255) / 256), dim3(256), 0, c->stream, q, sc.light_count, din, n);
     if (flags & RTX_RENDER_LANE_TRACE) hipLaunchKernelGGL((k_trace_fast<true>), dim3(c->trace_blocks_any), dim3(RTX_TRACE_BLOCK), 0, c->stream, sc, q, 0, 0);

@@ -132,11 +132,17 @@ struct DevQueues {
     float4 * n3;   // bits(lit rank), bits(pixel), bits(parent slot | refraction<<31), -
     float4 * c0;   // reflection child's returned colour (written by the child's k_resolve)
     float4 * c1;   // refraction child's returned colour, refraction child's hit distance
-    // shadow records
-    float4 *   s0; // origin.xyz, max distance
-    float4 *   s1; // direction.xyz, -
-    float4 *   sc; // unshadowed light contribution.xyz, -
-    uint32_t * socc; // 1 = occluded
+    // shadow rays: the hit's point and normal once per lit hit (level slot); a ray towards light L is DERIVED from the point and the light by its
+    // consumers (shadow_ray_of_light, rtx_trace.h — the arithmetic of Raytracer.cpp:155-198, the same bits wherever it is evaluated), the light's
+    // contribution by k_resolve for the lights that turn out unoccluded.  Per (light, hit) only the occlusion flag is stored.
+    float4 *   sp; // hit point.xyz, -
+    float4 *   sn; // hit normal.xyz, -
+    uint32_t * socc; // 1 = occluded (with RTX_RENDER_CULL_DEAD_SHADOW_RAYS also pre-set by the shading pass: 1 = contributes nothing, do not trace; 0 = trace)
+    // explicit shadow rays (rtx_debug_occluded only): origin.xyz + max distance, direction.xyz
+    float4 *   s0;
+    float4 *   s1;
+    int32_t    shadow_explicit;   // 1: the shadow-ray kernels read s0 / s1 instead of deriving the rays
+    int32_t    cull;              // 1: socc was pre-set by the shading pass (see above)
 
     int32_t *     spill;          // traversal stack spill, 3 regions of [(entry - RTX_LDS_STACK) * spill_threads + thread]: closest entries, closest keys, shadow entries
     int32_t       spill_threads;

@@ -1830,6 +1830,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
         W.best_prim = PRIM_NONE; W.best_tri = 0; W.best_u = 0.0f; W.best_v = 0.0f;
         bool clipped = false;
         uint32_t pix_idx = 0;
+        int any_level = 0, any_light = 0; uint32_t any_rank = 0;
         if (ANY) {
             uint32_t local = pk; int d = level;
             uint32_t lit_n = shadow_slots(ctr, q, d), seg = (lit_n + 63u) >> 6;
@@ -1837,10 +1838,10 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
             uint32_t light = 0; while (local >= seg && light + 1u < (uint32_t)nL) { local -= seg; light++; }      // wave-uniform, at most light_count - 1 rounds: no integer division on the VALU
             const uint32_t rank = local * 64u + (uint32_t)lane;
             W.valid = rank < lit_n && shadow_slot_is_lit(q, d, rank);      // the shadow rays of the 64 rays of the level's packet `local % seg`
+            any_level = d; any_light = (int)light; any_rank = rank;
             if (W.valid) {
                 out_slot = (uint32_t)q.shadow_base[d] + light * (uint32_t)q.level_cap[d] + rank;
-                const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot];
-                wo = V3(s0.x, s0.y, s0.z); W.ray.tcur = s0.w; wd = V3(s1.x, s1.y, s1.z);
+                load_shadow_ray(sc, q, d, (int)light, rank, out_slot, wo, wd, W.ray.tcur);      // derived from the hit's point and the packet's light (wave-uniform: scalar loads)
                 if (W.ray.tcur < 0.0f) W.valid = false;          // culled by k_shade<.., CULL>: contribution exactly zero, already resolved
             }
         } else {
@@ -1864,7 +1865,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
         auto world = [&](v3 & o, v3 & d) {
             o = V3(0.0f, 0.0f, 0.0f); d = V3(1.0f, 1.0f, 1.0f);
             if (!W.valid) return;
-            if (ANY) { const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot]; o = V3(s0.x, s0.y, s0.z); d = V3(s1.x, s1.y, s1.z); }
+            if (ANY) { float tm; load_shadow_ray(sc, q, any_level, any_light, any_rank, out_slot, o, d, tm); }
             else if (level == 0) { int px, py; primary_pixel(sc, q, pix_idx, px, py); RayFull r; primary_ray(sc, px, py, r, false); o = r.o; d = r.d; }
             else { const float4 r0 = q.r0[out_slot], r1 = q.r1[out_slot]; o = V3(r0.x, r0.y, r0.z); d = V3(r0.w, r1.x, r1.y); }
         };

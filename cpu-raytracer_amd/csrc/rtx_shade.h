@@ -156,6 +156,36 @@ RTX_D v3 light_calc(v3 colour, v3 normal, v3 to_light, v3 to_camera) {
     return vmuls(colour, intensity);
 }
 
+// The unshadowed contribution of light L (point, spot, directional: Raytracer.cpp:155-198 with PointLight.h:9-11, SpotLight.h:17-33,
+// DirectionalLight.h:9-11) to a hit: the expressions of the reference in its order, evaluated where the value is needed.
+RTX_D v3 light_contribution(const DevScene & sc, const int L, const v3 point, const v3 normal, const v3 to_camera) {
+    if (L < sc.point_light_count) {
+        const rtx_point_light & pl = sc.point_lights[L];
+        v3 to_light = vsub(v3p(pl.position), point);
+        const float d2 = vdot(to_light, to_light);
+        const float d  = sqrtf(d2);
+        to_light = vdivs(to_light, d);
+        return vdivs(light_calc(v3p(pl.colour), normal, to_light, to_camera), d2);
+    }
+    if (L < sc.point_light_count + sc.spot_light_count) {
+        const rtx_spot_light & sl = sc.spot_lights[L - sc.point_light_count];
+        v3 to_light = vsub(v3p(sl.position), point);
+        const float d2 = vdot(to_light, to_light);
+        const float d  = sqrtf(d2);
+        to_light = vdivs(to_light, d);
+        v3 c = V3(0.0f, 0.0f, 0.0f);
+        const float dt = vdot(to_light, v3p(sl.negative_direction));
+        if (dt > sl.outer_cutoff) {
+            float falloff = (dt - sl.outer_cutoff) / (sl.inner_cutoff - sl.outer_cutoff);
+            falloff = (falloff > 1.0f) ? 1.0f : falloff;
+            c = vmuls(vdivs(light_calc(v3p(sl.colour), normal, to_light, to_camera), d2), falloff);
+        }
+        return c;
+    }
+    const rtx_directional_light & dl = sc.dir_lights[L - sc.point_light_count - sc.spot_light_count];
+    return light_calc(v3p(dl.colour), normal, v3p(dl.negative_direction), to_camera);
+}
+
 // CULL: a light whose unshadowed contribution is exactly (0,0,0) (N.L <= 0, Light.h:17-18, or outside the spot cone,
 // SpotLight.h:25-26) cannot change the pixel whether or not it is occluded (diffuse + 0 == diffuse).  With CULL the shadow
 // ray is still COUNTED (the reference counts before testing, Raytracer.cpp:163,180,192) but marked so that k_trace<any>
@@ -241,52 +271,17 @@ RTX_D void shade_ray(const DevScene & sc, const DevQueues & q, const int level, 
     const bool lit = (flags & NF_LIT) != 0;
     const int lit_rank = (int)idx;
     if (lit) {
-        const v3 to_camera = vnormalize(vsub(v3p(sc.cam_pos), h.point));     // Raytracer.cpp:152 (camera, not ray origin)
-        int L = 0;
-        for (int i = 0; i < sc.point_light_count; i++, L++) {                 // :155-169
-            const rtx_point_light & pl = sc.point_lights[i];
-            v3 to_light = vsub(v3p(pl.position), h.point);
-            const float d2 = vdot(to_light, to_light);
-            const float d  = sqrtf(d2);
-            to_light = vdivs(to_light, d);
-            const v3 c = vdivs(light_calc(v3p(pl.colour), h.normal, to_light, to_camera), d2);   // PointLight.h:9-11
-            const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
-            const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
-            q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : d);
-            q.s1[s] = make_float4(to_light.x, to_light.y, to_light.z, 0.0f);
-            q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
-            if (dead) q.socc[s] = 1u;
-        }
-        for (int i = 0; i < sc.spot_light_count; i++, L++) {                  // :172-186
-            const rtx_spot_light & sl = sc.spot_lights[i];
-            v3 to_light = vsub(v3p(sl.position), h.point);
-            const float d2 = vdot(to_light, to_light);
-            const float d  = sqrtf(d2);
-            to_light = vdivs(to_light, d);
-            v3 c = V3(0.0f, 0.0f, 0.0f);                                      // SpotLight.h:17-33
-            const float dt = vdot(to_light, v3p(sl.negative_direction));
-            if (dt > sl.outer_cutoff) {
-                float falloff = (dt - sl.outer_cutoff) / (sl.inner_cutoff - sl.outer_cutoff);
-                falloff = (falloff > 1.0f) ? 1.0f : falloff;
-                c = vmuls(vdivs(light_calc(v3p(sl.colour), h.normal, to_light, to_camera), d2), falloff);
+        // the shadow rays themselves are not written: point and normal once per hit; shadow_ray_of_light (rtx_trace.h) derives the ray of each light
+        // where it is traced, k_resolve evaluates Light::calc_lighting for the lights that turn out unoccluded (light_contribution below)
+        q.sp[slot] = make_float4(h.point.x, h.point.y, h.point.z, 0.0f);
+        q.sn[slot] = make_float4(h.normal.x, h.normal.y, h.normal.z, 0.0f);
+        if (CULL) {
+            const v3 to_camera = vnormalize(vsub(v3p(sc.cam_pos), h.point));     // Raytracer.cpp:152 (camera, not ray origin)
+            for (int L = 0; L < nL; L++) {
+                const v3 c = light_contribution(sc, L, h.point, h.normal, to_camera);
+                const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
+                q.socc[s] = (c.x == 0.0f && c.y == 0.0f && c.z == 0.0f) ? 1u : 0u;      // 1: contributes exactly nothing whether occluded or not: not traced
             }
-            const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
-            const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
-            q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : d);
-            q.s1[s] = make_float4(to_light.x, to_light.y, to_light.z, 0.0f);
-            q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
-            if (dead) q.socc[s] = 1u;
-        }
-        for (int i = 0; i < sc.dir_light_count; i++, L++) {                   // :189-198
-            const rtx_directional_light & dl = sc.dir_lights[i];
-            const v3 nd = v3p(dl.negative_direction);
-            const v3 c = light_calc(v3p(dl.colour), h.normal, nd, to_camera);
-            const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + (uint32_t)lit_rank;
-            const bool dead = CULL && c.x == 0.0f && c.y == 0.0f && c.z == 0.0f;
-            q.s0[s] = make_float4(h.point.x, h.point.y, h.point.z, dead ? -1.0f : INFINITY);
-            q.s1[s] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-            q.sc[s] = make_float4(c.x, c.y, c.z, 0.0f);
-            if (dead) q.socc[s] = 1u;
         }
     }
     T.n_shadow += (uint32_t)nL * (uint32_t)__popcll(__ballot(lit));           // counted before the occlusion test (:163,180,192)
@@ -506,12 +501,14 @@ void k_resolve(const DevScene sc, const DevQueues q, const int level) {
             v3 result = V3(0.0f, 0.0f, 0.0f);
             if (flags & NF_LIT) {                                      // :146-200
                 const uint32_t rank = idx;                          // a hit's shadow rays sit in the hit's own slot of every light's segment
+                const float4 pp = q.sp[slot], nn = q.sn[slot];
+                const v3 point = V3(pp.x, pp.y, pp.z), normal = V3(nn.x, nn.y, nn.z);
+                const v3 to_camera = vnormalize(vsub(v3p(sc.cam_pos), point));     // Raytracer.cpp:152
                 v3 diffuse = v3p(sc.ambient);
                 for (int L = 0; L < nL; L++) {
                     const uint32_t s = (uint32_t)q.shadow_base[level] + (uint32_t)L * (uint32_t)lit_cap + rank;
                     if (q.socc[s]) continue;
-                    const float4 c = q.sc[s];
-                    diffuse = vadd(diffuse, V3(c.x, c.y, c.z));
+                    diffuse = vadd(diffuse, light_contribution(sc, L, point, normal, to_camera));      // :166-168, :183-185, :195-197 for the lights the hit can see
                 }
                 result = vmadd_v(diffuse, albedo, result);
             }

@@ -172,6 +172,32 @@ RTX_D float plane_t(const rtx_plane & pl, v3 o, v3 d) {
 
 // Shadow queue of a level: one slot per ray of the level and light (slot = the ray's own index: k_shade does not compact), of which
 // only the rays with a lit hit carry a shadow ray — NF_LIT in the node record k_shade wrote.
+// The shadow ray of light L (point lights, then spot lights, then directional ones: the order of Raytracer.cpp:155-198) for a hit at `point`:
+// direction to the light and the distance the ray may travel.  ONE definition for every consumer: the bits of a derived ray do not depend on who derives it.
+RTX_D void shadow_ray_of_light(const DevScene & sc, const int L, const v3 point, v3 & dir, float & dist) {
+    if (L < sc.point_light_count) {
+        v3 to_light = vsub(v3p(sc.point_lights[L].position), point);
+        const float d2 = vdot(to_light, to_light);
+        const float d  = sqrtf(d2);
+        dir = vdivs(to_light, d); dist = d;
+    } else if (L < sc.point_light_count + sc.spot_light_count) {
+        v3 to_light = vsub(v3p(sc.spot_lights[L - sc.point_light_count].position), point);
+        const float d2 = vdot(to_light, to_light);
+        const float d  = sqrtf(d2);
+        dir = vdivs(to_light, d); dist = d;
+    } else {
+        dir = v3p(sc.dir_lights[L - sc.point_light_count - sc.spot_light_count].negative_direction); dist = INFINITY;
+    }
+}
+// origin, direction and maximum distance of the shadow ray in shadow slot `out_slot` = (level, light, rank); a negative distance = not to be traced
+RTX_D void load_shadow_ray(const DevScene & sc, const DevQueues & q, const int level, const int light, const uint32_t rank, const uint32_t out_slot, v3 & o, v3 & d, float & tmax) {
+    if (q.shadow_explicit) { const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot]; o = V3(s0.x, s0.y, s0.z); tmax = s0.w; d = V3(s1.x, s1.y, s1.z); return; }
+    const float4 p = q.sp[(uint32_t)q.level_base[level] + rank];
+    o = V3(p.x, p.y, p.z);
+    shadow_ray_of_light(sc, light, o, d, tmax);
+    if (q.cull && q.socc[out_slot] != 0u) tmax = -1.0f;          // k_shade<.., CULL>: this light contributes exactly nothing to this hit
+}
+
 RTX_D uint32_t shadow_slots(const DevCounters * ctr, const DevQueues & q, int level) {
     const uint32_t n = ctr->ray_count[level], cap = (uint32_t)q.level_cap[level];
     return n < cap ? n : cap;
@@ -249,7 +275,7 @@ void k_trace(const DevScene sc, const DevQueues q, const int level) {
                     const uint32_t light = idx / lit_n, rank = idx - light * lit_n;
                     out_slot = (uint32_t)q.shadow_base[level] + light * (uint32_t)lit_cap + rank;
                     live = shadow_slot_is_lit(q, level, rank);
-                    if (live) { const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot]; wo = V3(s0.x, s0.y, s0.z); tcur = s0.w; wd = V3(s1.x, s1.y, s1.z); }
+                    if (live) { load_shadow_ray(sc, q, level, (int)light, rank, out_slot, wo, wd, tcur); if (tcur < 0.0f) live = false; }
                 } else {
                     out_slot = (uint32_t)q.level_base[level] + idx;
                     if (level == 0) {
@@ -492,8 +518,7 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
                     const uint32_t light = local / lit_n, rank = local - light * lit_n;
                     out_slot = (uint32_t)q.shadow_base[d] + light * (uint32_t)q.level_cap[d] + rank;
                     live = shadow_slot_is_lit(q, d, rank);
-                    if (live) { const float4 s0 = q.s0[out_slot], s1 = q.s1[out_slot]; wo = V3(s0.x, s0.y, s0.z); tcur = s0.w; wd = V3(s1.x, s1.y, s1.z); }
-                    if (tcur < 0.0f) live = false;        // culled by k_shade<.., CULL>: contribution is exactly zero, already resolved
+                    if (live) { load_shadow_ray(sc, q, d, (int)light, rank, out_slot, wo, wd, tcur); if (tcur < 0.0f) live = false; }      // negative: culled by k_shade<.., CULL> (contribution exactly zero)
                 } else {
                     out_slot = (uint32_t)q.level_base[level] + idx;
                     if (level == 0) {
