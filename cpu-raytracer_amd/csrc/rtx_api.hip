@@ -612,11 +612,11 @@ static int alloc_queues(rtx_ctx * c, int batch_tiles) {
     int rc = 0, k = 0;
     // rays of level 0 are never stored, but the arrays are indexed by global slot for simplicity of addressing
     void ** f4[] = { (void **)&c->q.r0, (void **)&c->q.r1, (void **)&c->q.r2, (void **)&c->q.r3, (void **)&c->q.r4, (void **)&c->q.h0,
-                     (void **)&c->q.n0, (void **)&c->q.n1, (void **)&c->q.n2, (void **)&c->q.n3, (void **)&c->q.c0, (void **)&c->q.c1,
+                     (void **)&c->q.n0, (void **)&c->q.n1, (void **)&c->q.n2, (void **)&c->q.c0, (void **)&c->q.c1,
                      (void **)&c->q.sp, (void **)&c->q.sn };
     for (void ** p : f4) { if (!rc) rc = ensure(c, c->qb[k], slots * 16); *p = c->qb[k].p; k++; }
     if (!rc) rc = ensure(c, c->qb[k], slots * 4); c->q.h1 = (int32_t *)c->qb[k].p; k++;
-    c->q.s0 = c->q.s1 = nullptr; c->q.shadow_explicit = 0; c->q.cull = 0;      // explicit shadow rays: rtx_debug_occluded allocates them (debug_explicit_rays)
+    c->q.n3 = nullptr; c->q.s0 = c->q.s1 = nullptr; c->q.shadow_explicit = 0; c->q.cull = 0;      // explicit shadow rays: rtx_debug_occluded allocates them (debug_explicit_rays)
     if (!rc) rc = ensure(c, c->qb[k], sslots * 4); c->q.socc = (uint32_t *)c->qb[k].p; k++;
     c->q.spill = (int32_t *)c->d_spill.p;
     c->q.counters = (DevCounters *)c->d_counters.p;

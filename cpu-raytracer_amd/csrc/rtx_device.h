@@ -129,7 +129,7 @@ struct DevQueues {
     float4 * n0;   // albedo.xyz (or sky colour on a miss), bits(flags)
     float4 * n1;   // Ks.xyz, F_r
     float4 * n2;   // (Kt - 1).xyz, hit distance
-    float4 * n3;   // bits(lit rank), bits(pixel), bits(parent slot | refraction<<31), -
+    float4 * n3;   // unused since round 3 (pixel: from the slot at level 0; parent: ray record r1.w)
     float4 * c0;   // reflection child's returned colour (written by the child's k_resolve)
     float4 * c1;   // refraction child's returned colour, refraction child's hit distance
     // shadow rays: the hit's point and normal once per lit hit (level slot); a ray towards light L is DERIVED from the point and the light by its

@@ -365,10 +365,11 @@ RTX_D void shade_ray(const DevScene & sc, const DevQueues & q, const int level, 
     if (valid) {
         q.n0[slot] = make_float4(albedo.x, albedo.y, albedo.z, as_f(flags));
         if (flags & NF_HIT) {
-            q.n1[slot] = make_float4(Ks.x, Ks.y, Ks.z, F_r);
-            q.n2[slot] = make_float4(absorption.x, absorption.y, absorption.z, t);
+            // Ks / F_r / absorption are only read back where the hit reflects or refracts, the hit distance only by a refraction ray's parent (Beer's law):
+            // most hits (72 % of the cfg3 frame's) need neither record
+            if (flags & (NF_REFL | NF_REFR)) q.n1[slot] = make_float4(Ks.x, Ks.y, Ks.z, F_r);
+            if ((flags & NF_REFR) || (level > 0 && ((uint32_t)parent & 0x80000000u))) q.n2[slot] = make_float4(absorption.x, absorption.y, absorption.z, t);
         }
-        q.n3[slot] = make_float4(as_f(lit_rank), as_f(pixel), as_f(parent), 0.0f);
     }
 }
 
@@ -490,13 +491,17 @@ void k_resolve(const DevScene sc, const DevQueues q, const int level) {
         const float4 n0 = q.n0[slot];
         const int flags = as_i(n0.w);
         if (flags & NF_CLIP) continue;                                // clipped pixel of an edge tile
-        const float4 n3 = q.n3[slot];
+        // where the colour goes: a primary ray's pixel follows from its slot, a secondary ray's parent travels in its ray record
+        uint32_t parent = 0u;
+        if (level > 0) parent = (uint32_t)as_i(q.r1[slot].w);
         v3 colour; float distance;
         if (!(flags & NF_HIT)) {
             colour = V3(n0.x, n0.y, n0.z);                             // sky, Raytracer.cpp:106-110
             distance = INFINITY;
         } else {
-            const float4 n1 = q.n1[slot], n2 = q.n2[slot];
+            float4 n1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n2 = n1;
+            if (flags & (NF_REFL | NF_REFR)) n1 = q.n1[slot];
+            if ((flags & NF_REFR) || (parent & 0x80000000u)) n2 = q.n2[slot];
             const v3 albedo = V3(n0.x, n0.y, n0.z);
             v3 result = V3(0.0f, 0.0f, 0.0f);
             if (flags & NF_LIT) {                                      // :146-200
@@ -544,13 +549,13 @@ void k_resolve(const DevScene sc, const DevQueues q, const int level) {
         if (level == 0 && q.tm_packed) {
             q.tm_packed[(uint32_t)q.tm_base + idx] = plot_pack(colour);        // tile-major: slot order, one coalesced store per wave
         } else if (level == 0) {
-            const int pixel = as_i(n3.y);
+            int px, py; primary_pixel(sc, q, idx, px, py);
+            const int pixel = py * sc.width + px;
             q.fb_rgb[3 * (size_t)pixel + 0] = colour.x;
             q.fb_rgb[3 * (size_t)pixel + 1] = colour.y;
             q.fb_rgb[3 * (size_t)pixel + 2] = colour.z;
             q.fb_packed[pixel] = plot_pack(colour);
         } else {
-            const uint32_t parent = (uint32_t)as_i(n3.z);
             const uint32_t ps = parent & 0x7fffffffu;
             if (parent & 0x80000000u) q.c1[ps] = make_float4(colour.x, colour.y, colour.z, distance);
             else                      q.c0[ps] = make_float4(colour.x, colour.y, colour.z, 0.0f);
