@@ -341,3 +341,21 @@ def test_split_shadow_walk_changes_nothing(api, name, split, monkeypatch):
     for mode in ({}, {"serial": True}, {"serial": True, "cull_dead_shadow_rays": True}):
         cmp = util.compare_to_golden(r.render(**mode), g)
         assert cmp["stats_equal"] and cmp["max_abs"] == 0.0 and cmp["n_diff_pixels"] == 0 and cmp["packed_mismatch"] == 0, (mode, cmp)
+
+
+@pytest.mark.parametrize("knobs", [{"RTX_FUSE_SHADE": "1"}, {"RTX_PK_CLOSEST_ASM": "0", "RTX_PK_DEFER_PRIMARY": "8"}, {"RTX_PK_DEFER_PRIMARY": "64"},
+                                   {"RTX_PK_DEFER_PRIMARY": "1", "RTX_PK_DEFER_CLOSEST": "2"}, {"RTX_PK_DEFER_PRIMARY": "16", "RTX_PK_DEFER_CLOSEST": "16", "RTX_LANE_FROM_LEVEL": "99"}],
+                         ids=["fused_shade", "compiled_shared_walk", "all_private", "share_everything", "share_all_levels_packets_everywhere"])
+@pytest.mark.parametrize("name", ["materials_aniso", "dynamic", "tori16", "materials_b5", "materials_naive"])
+def test_closest_hit_walk_variants_change_nothing(api, name, knobs, monkeypatch):
+    """Round 3's closest-hit choices are scheduling decisions: the hand-scheduled shared walk (pk_blas_closest_asm) with any hand-over
+    threshold, for primary packets only or for every level, the compiled shared walk it replaced (RTX_PK_CLOSEST_ASM=0), every lane private,
+    and the opt-in fused trace-and-shade kernel (RTX_FUSE_SHADE=1: child slots from wave-private chunks, unused slots marked as holding no
+    ray) — always the reference's frame and ray counts, in both launch shapes."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    sc, g = util.load_golden(name)
+    r = api.Renderer(sc)
+    for mode in ({}, {"serial": True}, {"serial": True, "cull_dead_shadow_rays": True}):
+        cmp = util.compare_to_golden(r.render(**mode), g)
+        assert cmp["stats_equal"] and cmp["max_abs"] == 0.0 and cmp["n_diff_pixels"] == 0 and cmp["packed_mismatch"] == 0, (knobs, mode, cmp)
