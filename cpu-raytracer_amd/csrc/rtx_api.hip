@@ -59,7 +59,7 @@ struct Knobs {
     int split_items;             // RTX_PK_SPLIT           split shadow-ray walk: 0 = off, else the smallest item chunk
     int resolve_block;           // RTX_RESOLVE_BLOCK      k_resolve workgroup size
     int pk4_order;               // RTX_PK4_ORDER          slot order of the 4-wide records (0: smallest stack need first)
-    bool merge_any, no_wide, fail_item_alloc;
+    bool merge_any, no_wide, no_wide_closest, fail_item_alloc;
     bool fuse_shade;             // RTX_FUSE_SHADE         the closest-hit packet kernel shades its own hits (0: a k_shade launch per level)
 };
 
@@ -211,6 +211,59 @@ static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, st
     return true;
 }
 
+// The closest-hit per-lane walk's 4-wide records (rtx_packet.h, pk_lane_phase_closest).  BottomLevelBVH::trace (BottomLevelBVH.cpp:355-396)
+// tests every node once, when it is popped, against the closest distance of that moment, and pushes an inner node's children untested, far
+// child first.  With nested boxes (see build_nodes_pk4: AABB::intersect is monotone under nesting in floating point) a node that passes at
+// its pop has a parent that passed at its own — earlier, hence against a distance at least as large — so the test of an inner child L of
+// node X can be skipped: its children LL, LR meet, at THEIR pops, exactly the closest distances they meet in the reference (no leaf is visited
+// between the pop of L and the pop of its near child), pass or fail as there, and reach the same leaves in the same order provided the four
+// grandchildren are taken in the order the two binary levels would take them: X's near child's near child first.  The record of inner node
+// j keeps the tree's shape for that: slots 0-1 = the left child's children (or the left child itself, a leaf, in slot 0), slots 2-3 the
+// right child's; the near / far axes of the two children ride in slots 0 and 2.  Half the dependent fetches per walk.
+//   record (128 B, at byte offset 64 * left-child index of j): 4 x { (min.xyz, first) (max.xyz, meta) },
+//   meta = leaf count (< 16) | axis of the slot's PARENT (slots 0 and 2; 0: the parent is a leaf, i.e. the slot itself) << 26 | axis of the slot node << 30;
+//   unused slots hold a point box, which never passes.  *stack_need = pending entries a lane's walk can have (bound over all visiting orders).
+static bool build_nodes_pk4c(const rtx_bvh_node * nodes, int n, int tri_count, std::vector<float4> & out, int * stack_need) {
+    if (n >= (1 << 24) || tri_count >= (1 << 24)) return false;
+    auto inside = [&](int c, int p) {
+        for (int a = 0; a < 3; a++) if (!(nodes[c].aabb_min[a] >= nodes[p].aabb_min[a] && nodes[c].aabb_max[a] <= nodes[p].aabb_max[a])) return false;
+        return true;
+    };
+    std::vector<int> order, stack(1, 0);
+    while (!stack.empty()) {
+        const int i = stack.back(); stack.pop_back();
+        const int cnt = nodes[i].count & 0x3fffffff, f = nodes[i].left_or_first;
+        if (cnt > 0) { if (cnt >= 16) return false; continue; }      // work-list and stack entries pack (first, count) into one word
+        if (f & 1) return false;                                   // records are addressed by left / 2
+        if (!inside(f, i) || !inside(f + 1, i)) return false;      // nesting
+        order.push_back(i); stack.push_back(f); stack.push_back(f + 1);
+    }
+    out.assign((size_t)4 * (n > 0 ? n : 1) + 8, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    std::vector<int> need((size_t)n, 0);
+    for (size_t k = order.size(); k-- > 0; ) {                      // children before parents
+        const int j = order[k], l = nodes[j].left_or_first;
+        float4 * rec = &out[(size_t)4 * l];
+        int nd = 0, ns = 0;
+        for (int g = 0; g < 2; g++) {
+            const rtx_bvh_node & c = nodes[l + g];
+            const bool leaf = (c.count & 0x3fffffff) > 0;
+            const int slots = leaf ? 1 : 2;
+            for (int t = 0; t < slots; t++) {
+                const int si = leaf ? l + g : c.left_or_first + t;
+                const rtx_bvh_node & sn = nodes[si];
+                const uint32_t meta = ((uint32_t)sn.count & 0x3fffffffu) | (t == 0 && !leaf ? (((uint32_t)c.count >> 30) << 26) : 0u) | (((uint32_t)sn.count >> 30) << 30);
+                float f, m; memcpy(&f, &sn.left_or_first, 4); memcpy(&m, &meta, 4);
+                rec[2 * (2 * g + t)]     = make_float4(sn.aabb_min[0], sn.aabb_min[1], sn.aabb_min[2], f);
+                rec[2 * (2 * g + t) + 1] = make_float4(sn.aabb_max[0], sn.aabb_max[1], sn.aabb_max[2], m);
+                nd = std::max(nd, need[si]); ns++;
+            }
+        }
+        need[j] = nd + ns - 1;                                      // any slot may come first, with the others pending
+    }
+    *stack_need = need[0];
+    return true;
+}
+
 extern "C" int rtx_abi_version(void) { return RTX_ABI_VERSION; }
 
 extern "C" const char * rtx_last_error(const rtx_ctx * ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -284,6 +337,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     K.pk4_order = (int)knob_int("RTX_PK4_ORDER", 1, 0, 1);
     K.merge_any = knob_int("RTX_SERIAL_MERGE_ANY", 1, 0, 1) != 0;       // one-stream mode: ONE shadow-ray launch for all levels after the last shade (0: one per level)
     K.no_wide = knob_int("RTX_PK_WIDE", 1, 0, 1) == 0;                  // 0: binary shadow-ray walk for every mesh
+    K.no_wide_closest = knob_int("RTX_PK_WIDE_CLOSEST", 1, 0, 1) == 0;  // 0: binary per-lane phase of the closest-hit walk for every mesh
     K.fuse_shade = knob_int("RTX_FUSE_SHADE", 0, 0, 1) != 0;      // measured: 1.51 vs 1.28 ms per cfg3 frame with three frames in flight: off
     K.fail_item_alloc = knob_int("RTX_DEBUG_FAIL_ITEM_ALLOC", 0, 0, 1) != 0;      // tests: the item buffer's allocation fails (a size no device has), the fallback kernel must take over
     int bpc = 0;
@@ -400,7 +454,10 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
     std::vector<float4> ndp; convert_nodes_pk(nodes, node_count, ndp);
     std::vector<float4> nd4; int need4 = 0;
     const bool wide = !c->knobs.no_wide && build_nodes_pk4(nodes, node_count, triangle_count, nd4, &need4, c->knobs.pk4_order) && need4 <= RTX_PK4_MAX_NEED;
-    void * dn = nullptr, * dt = nullptr, * dc = nullptr, * dnp = nullptr, * dn4 = nullptr;
+    std::vector<float4> nd4c; int need4c = 0;
+    const bool wide_closest = !c->knobs.no_wide_closest && build_nodes_pk4c(nodes, node_count, triangle_count, nd4c, &need4c) && need4c <= RTX_MAX_STACK - 2;
+    void * dn = nullptr, * dt = nullptr, * dc = nullptr, * dnp = nullptr, * dn4 = nullptr, * dn4c = nullptr;
+    if (wide_closest) { HIP_OK(c, hipMalloc(&dn4c, nd4c.size() * 16)); c->blas_allocs[blas_id].push_back(dn4c); HIP_OK(c, hipMemcpy(dn4c, nd4c.data(), nd4c.size() * 16, hipMemcpyHostToDevice)); }
     if (wide) { HIP_OK(c, hipMalloc(&dn4, nd4.size() * 16)); c->blas_allocs[blas_id].push_back(dn4); HIP_OK(c, hipMemcpy(dn4, nd4.data(), nd4.size() * 16, hipMemcpyHostToDevice)); }
     HIP_OK(c, hipMalloc(&dn, nd.size() * 16)); c->blas_allocs[blas_id].push_back(dn);
     HIP_OK(c, hipMalloc(&dnp, ndp.size() * 16)); c->blas_allocs[blas_id].push_back(dnp);
@@ -420,8 +477,8 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
     c->blas_packet_ok[blas_id] = (leaf_max < 65536 && node_count < (1 << 26) && triangle_count < (1 << 25)) ? 1 : 0;
     DevBlas & B = c->h_blas[blas_id];
     B.nodes = (const float4 *)dn; B.pk_nodes = (const float4 *)dnp; B.tri_hot = (const float4 *)dt; B.tri_cold = (const rtx_triangle_cold *)dc;
-    B.pk4_nodes = (const float4 *)dn4;
-    B.node_count = node_count; B.tri_count = triangle_count; B.material_offset = material_offset; B.pk4_need = wide ? need4 : -1;
+    B.pk4_nodes = (const float4 *)dn4; B.pk4c_nodes = (const float4 *)dn4c;
+    B.node_count = node_count; B.tri_count = triangle_count; B.material_offset = material_offset; B.pk4_need = wide ? need4 : -1; B.pk4c_need = wide_closest ? need4c : -1;
     return upload(c, c->d_blas, c->h_blas.data(), c->h_blas.size() * sizeof(DevBlas));
 }
 
@@ -1049,6 +1106,13 @@ __global__ void k_debug_sky(const float * sky, int size, const float * dirs, flo
 extern "C" int rtx_debug_blas_wide(rtx_ctx * c, int32_t blas_id, int32_t * stack_need) {
     if (!c || !stack_need || blas_id < 0 || (size_t)blas_id >= c->h_blas.size() || !c->h_blas[blas_id].nodes) return RTX_ERR_INVALID_ARG;
     *stack_need = c->h_blas[blas_id].pk4_nodes ? c->h_blas[blas_id].pk4_need : -1;
+    return RTX_OK;
+}
+
+// which per-lane closest-hit walk an uploaded mesh gets: the stack need of its ordered 4-wide records, or -1 for the binary walk
+extern "C" int rtx_debug_blas_wide_closest(rtx_ctx * c, int32_t blas_id, int32_t * stack_need) {
+    if (!c || !stack_need || blas_id < 0 || (size_t)blas_id >= c->h_blas.size() || !c->h_blas[blas_id].nodes) return RTX_ERR_INVALID_ARG;
+    *stack_need = c->h_blas[blas_id].pk4c_nodes ? c->h_blas[blas_id].pk4c_need : -1;
     return RTX_OK;
 }
 

@@ -23,8 +23,8 @@ static __device__ __forceinline__ float3 gld3(rtx_gptr p, int i) {
 }
 
 #define RTX_MAX_LEVELS   12          // NUMBER_OF_BOUNCES + 1 wavefront levels supported
-#ifndef RTX_LDS_STACK
 #define RTX_TRI_STRIDE   4           // float4 per hot triangle on the device: p0, e1, e2 + padding = one 64-byte line per triangle
+#ifndef RTX_LDS_STACK
 #define RTX_LDS_STACK    16          // traversal stack entries kept in LDS per lane (4 KiB per wave); deeper entries spill to HBM
 #endif
 #define RTX_WAVE         64
@@ -54,7 +54,8 @@ struct DevBlas {
     const float4 *            tri_hot;    // RTX_TRI_STRIDE x float4 per triangle: (p0, -) (e1, -) (e2, -) (padding)
     const rtx_triangle_cold * tri_cold;   // reference layout, 64 B
     const float4 *            pk4_nodes;  // 4-wide records for the shadow-ray packet walk (128 B at 64 * left-child index), or null: tree not nested / too big
-    int32_t node_count, tri_count, material_offset, pk4_need;
+    const float4 *            pk4c_nodes; // ordered 4-wide records for the closest-hit per-lane walk (build_nodes_pk4c, rtx_api.hip), or null
+    int32_t node_count, tri_count, material_offset, pk4_need, pk4c_need, pad_;
 };
 
 struct DevTexture {

@@ -124,7 +124,7 @@ RTX_D bool pk_slab(float4 q0, float4 q1, const PkRay & r) {
 #endif
 struct PkWalk {                      // everything a packet walk carries; wave-uniform unless noted
     rtx_cptr tlas, nodes, tris;
-    rtx_gptr lane_nodes, lane_tris;                      // the BLAS being walked in the per-lane kernels' layout (per-lane phases)
+    rtx_gptr lane_nodes, lane_nodes4c, lane_tris;                      // the BLAS being walked in the per-lane kernels' layout (per-lane phases)
     int sp, floor_sp, cur_inst, depth;
     int cur_idx, cur_first, cur_cnt;
     unsigned long long m, alive;
@@ -1067,13 +1067,19 @@ RTX_D void pk_lane_phase_any4(PkWalk & W, const int lane, const uint32_t lane_ld
 // "test the fetched box" (entries written by the compiled walk, which has no per-lane t_near at hand).
 #define PK_FIFO_PACKED 0x40000000
 #define PK_KEY_PASSED (-INFINITY)
-RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered, const PkHybrid & H, rtx_gptr nodes, rtx_gptr tris) {
+// WIDE: the inner step reads the ordered 4-wide record of the node (build_nodes_pk4c, rtx_api.hip: the four grandchildren in the tree's shape),
+// tests the four boxes and takes them in the order the two binary levels would — half the dependent fetches, and the two children's own tests
+// fall away (nested boxes: a grandchild that passes at its pop has a parent that would have passed at its own).
+template <bool WIDE>
+RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered, const PkHybrid & H, rtx_gptr nodes, rtx_gptr nodes4, rtx_gptr tris) {
     const int fifo_n = W.fifo_n;
     int fi = 0, sp = 0;
     int2 nxt = fifo_n > 0 ? H.fifo[0] : make_int2(0, 0);          // the next work-list entry is always in flight before it is needed
     const v3 co = V3(W.ray.o_xy.x, W.ray.o_xy.y, W.ray.o_zz.x), cd = W.ray.d, cinv = V3(W.ray.i_xy.x, W.ray.i_xy.y, W.ray.i_zz.x);
     float tcur = W.ray.tcur;
     bool have_cur = false; int cur_first = 0, cur_cnt = 0;
+    // BVHNode::should_visit_left_first per axis code (0: none / leaf, 1 x, 2 y, 3 z) as a bit set; BVH_TRAVERSE_TREE_NAIVE: always the left child first
+    const uint32_t pos_bits = ordered ? (1u | (cd.x > 0.0f ? 2u : 0u) | (cd.y > 0.0f ? 4u : 0u) | (cd.z > 0.0f ? 8u : 0u)) : 15u;
     auto push = [&](int e, float key) {
         if (sp < RTX_LDS_STACK) { H.stk[sp * RTX_WAVE] = e; H.stk_key[sp * RTX_WAVE] = key; }
         else if (sp < RTX_MAX_STACK) { H.spill[(sp - RTX_LDS_STACK) * H.spill_stride] = e; H.spill_key[(sp - RTX_LDS_STACK) * H.spill_stride] = key; }
@@ -1092,7 +1098,35 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
         const unsigned long long lp_a = LP_NOW();
 #endif
         // inner node: child-pair gather, both slab tests, the lane's own near / far order (BVHNode.h:30-40)
-        if (have_cur && (cur_cnt & 0x3fffffff) == 0) {
+        if (WIDE && have_cur && (cur_cnt & 0x3fffffff) == 0) {
+            const int base = 4 * cur_first;
+            const float4 a0 = gld(nodes4, base), a1 = gld(nodes4, base + 1), b0 = gld(nodes4, base + 2), b1 = gld(nodes4, base + 3);
+            const float4 c0 = gld(nodes4, base + 4), c1 = gld(nodes4, base + 5), d0 = gld(nodes4, base + 6), d1 = gld(nodes4, base + 7);
+            float k0, k1, k2, k3;
+            const bool p0 = slab_test_sel<true>(a0, a1, co, cinv, tcur, k0), p1 = slab_test_sel<true>(b0, b1, co, cinv, tcur, k1);
+            const bool p2 = slab_test_sel<true>(c0, c1, co, cinv, tcur, k2), p3 = slab_test_sel<true>(d0, d1, co, cinv, tcur, k3);
+            // a slot as a stack entry: its node's own (first, count, axis); a key of +inf marks a slot that failed (or is unused)
+            auto entry = [](const float4 & lo, const float4 & hi) { const uint32_t m = (uint32_t)as_i(hi.w); return (int)(0x40000000u | ((m >> 30) << 28) | ((m & 15u) << 24) | (uint32_t)as_i(lo.w)); };
+            int e0 = entry(a0, a1), e1 = entry(b0, b1), e2 = entry(c0, c1), e3 = entry(d0, d1);
+            k0 = p0 ? k0 : INFINITY; k1 = p1 ? k1 : INFINITY; k2 = p2 ? k2 : INFINITY; k3 = p3 ? k3 : INFINITY;
+            // the lane's own near / far order at the node and at its two children (BVHNode.h:30-40); axis 0 = a leaf child: one slot, no order
+            const bool lf_x = ((pos_bits >> ((uint32_t)cur_cnt >> 30)) & 1u) != 0u;
+            const bool lf_l = ((pos_bits >> (((uint32_t)as_i(a1.w) >> 26) & 3u)) & 1u) != 0u, lf_r = ((pos_bits >> (((uint32_t)as_i(c1.w) >> 26) & 3u)) & 1u) != 0u;
+            auto swap_if = [](const bool c, int & ea, float & ka, int & eb, float & kb) { const int te = c ? eb : ea; const float tk = c ? kb : ka; eb = c ? ea : eb; kb = c ? ka : kb; ea = te; ka = tk; };
+            swap_if(!lf_l, e0, k0, e1, k1);
+            swap_if(!lf_r, e2, k2, e3, k3);
+            swap_if(!lf_x, e0, k0, e2, k2);
+            swap_if(!lf_x, e1, k1, e3, k3);
+            // visiting order e0 .. e3: the first that passed is walked now, the others wait — the last one deepest — for the reference's pop-time test
+            const bool q0 = k0 < INFINITY, q1 = k1 < INFINITY, q2 = k2 < INFINITY, q3 = k3 < INFINITY;
+            if (q3 && (q0 | q1 | q2)) push(e3, k3);
+            if (q2 && (q0 | q1)) push(e2, k2);
+            if (q1 && q0) push(e1, k1);
+            const int e = q0 ? e0 : (q1 ? e1 : (q2 ? e2 : e3));
+            have_cur = q0 | q1 | q2 | q3;
+            cur_first = e & 0x00ffffff; cur_cnt = (int)((((uint32_t)e >> 28) & 3u) << 30) | ((e >> 24) & 15);
+        }
+        if (!WIDE && have_cur && (cur_cnt & 0x3fffffff) == 0) {
             const int left = cur_first;
             const float4 la = gld(nodes, 2 * left), lb = gld(nodes, 2 * left + 1), ra = gld(nodes, 2 * left + 2), rb = gld(nodes, 2 * left + 3);
             float kl = 0.0f, kr = 0.0f;
@@ -1629,7 +1663,8 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
         if (ANY && W.alive == 0ull) return true;
         if (W.floor_sp >= 0 && W.sp == W.floor_sp) {            // BottomLevelBVH::trace / intersect returned: back to world space
             if (!ANY && ASM && FAST && W.pub != W.alive) {       // closest-hit hybrid: the private lanes finish this instance on their own
-                pk_lane_phase_closest(W, lane, ordered, H, W.lane_nodes, W.lane_tris);
+                if (W.lane_nodes4c) pk_lane_phase_closest<true>(W, lane, ordered, H, W.lane_nodes, W.lane_nodes4c, W.lane_tris);
+                else pk_lane_phase_closest<false>(W, lane, ordered, H, W.lane_nodes, nullptr, W.lane_tris);
                 W.pub = W.alive;
             }
             if (W.sp == 0) return true;                         // nothing left in the TLAS: the world-space ray is not needed again
@@ -1663,7 +1698,7 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
             W.cur_blas = rfl(I.blas_id);
             const DevBlas & B = sc.blas[W.cur_blas];
             W.nodes = pk_cptr(B.pk_nodes); W.tris = pk_cptr(B.tri_hot); W.cur_inst = inst;
-            W.lane_nodes = RTX_GPTR(B.nodes); W.lane_tris = RTX_GPTR(B.tri_hot);
+            W.lane_nodes = RTX_GPTR(B.nodes); W.lane_tris = RTX_GPTR(B.tri_hot); if (!ANY) W.lane_nodes4c = RTX_GPTR(B.pk4c_nodes);
             W.floor_sp = W.sp; W.depth = 0;
             const float4 na = sld(W.nodes, 0), nb = sld(W.nodes, 1);            // BLAS root (BottomLevelBVH.cpp:360-370)
             const bool risky = FAST && __ballot(W.valid && !inv_is_finite(cinv)) != 0ull;

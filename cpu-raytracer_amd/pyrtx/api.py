@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "..", "csrc", "librtx_hip.so")
 EXPORTS = ["rtx_abi_version", "rtx_create", "rtx_destroy", "rtx_last_error", "rtx_upload_blas", "rtx_upload_materials",
            "rtx_upload_texture", "rtx_upload_sky", "rtx_set_frame", "rtx_render_tiles", "rtx_synchronize", "rtx_get_stats",
            "rtx_read_framebuffer", "rtx_framebuffer_device_ptrs", "rtx_last_kernel_times", "rtx_enable_kernel_timing",
-           "rtx_bind_framebuffer", "rtx_set_stream", "rtx_present", "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample", "rtx_debug_blas_wide",
+           "rtx_bind_framebuffer", "rtx_set_stream", "rtx_present", "rtx_debug_libm", "rtx_debug_texture_sample", "rtx_debug_sky_sample", "rtx_debug_blas_wide", "rtx_debug_blas_wide_closest",
            "rtx_group_unique_id", "rtx_group_create", "rtx_group_render", "rtx_group_destroy", "rtx_group_attach", "rtx_group_create_local", "rtx_group_render_local",
            "rtx_group_layout", "rtx_group_slot_pixels", "rtx_debug_group_loopback", "rtx_debug_trace_rays", "rtx_debug_occluded", "rtx_debug_light_plot"]
 
@@ -75,6 +75,7 @@ def load_library(path: Optional[str] = None):
     lib.rtx_debug_texture_sample.argtypes = [vp, i32, vp, vp, i32]
     lib.rtx_debug_sky_sample.argtypes = [vp, vp, vp, i32]
     lib.rtx_debug_blas_wide.argtypes = [vp, i32, vp]
+    lib.rtx_debug_blas_wide_closest.argtypes = [vp, i32, vp]
     lib.rtx_group_unique_id.argtypes = [vp]
     lib.rtx_group_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
     lib.rtx_group_attach.argtypes = [vp, vp, C.POINTER(vp)]
@@ -288,6 +289,11 @@ class Renderer:
     def debug_blas_wide(self, blas_id: int) -> int:
         need = C.c_int32(0)
         self._chk(self.lib.rtx_debug_blas_wide(self.ctx, blas_id, C.byref(need)), "rtx_debug_blas_wide")
+        return int(need.value)
+
+    def debug_blas_wide_closest(self, blas_id: int) -> int:
+        need = C.c_int32(0)
+        self._chk(self.lib.rtx_debug_blas_wide_closest(self.ctx, blas_id, C.byref(need)), "rtx_debug_blas_wide_closest")
         return int(need.value)
 
     def debug_occluded(self, origin_direction_maxdist7: np.ndarray, flags: int = 0) -> np.ndarray:

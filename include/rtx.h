@@ -373,6 +373,9 @@ int rtx_debug_group_loopback(rtx_ctx * ctx, int32_t world, uint32_t flags);
 /* the shadow-ray packet walk of an uploaded mesh: *stack_need = packet-stack entries its 4-wide records can need, or -1 when the mesh keeps
  * the binary walk (boxes not nested / limits exceeded) */
 int rtx_debug_blas_wide(rtx_ctx * ctx, int32_t blas_id, int32_t * stack_need);
+/* the per-lane part of the closest-hit packet walk of an uploaded mesh: *stack_need = stack entries a lane's walk of the ordered 4-wide records
+ * can need, or -1 when the mesh keeps the binary walk (boxes not nested / a leaf of 16+ triangles / 2^24+ nodes or triangles) */
+int rtx_debug_blas_wide_closest(rtx_ctx * ctx, int32_t blas_id, int32_t * stack_need);
 /* Sky::sample (Sky.cpp:28-68) of the uploaded sky at n directions */
 int rtx_debug_sky_sample(rtx_ctx * ctx, const float * directions_xyz, float * out_rgb, int32_t n);
 

@@ -291,6 +291,8 @@ def test_shadow_walk_uses_wide_records_for_reference_trees_and_binary_walk_other
         r = api.Renderer(sc)
         needs = [r.debug_blas_wide(i) for i in range(len(sc.blas))]
         assert all(0 <= n <= 36 for n in needs), (name, needs)
+        needs_c = [r.debug_blas_wide_closest(i) for i in range(len(sc.blas))]      # the closest-hit per-lane walk's ordered records (build_nodes_pk4c)
+        assert all(0 <= n <= 62 for n in needs_c), (name, needs_c)
     sc, g = util.load_golden("monkey_small")
     sc2 = copy.deepcopy(sc)
     rng = np.random.default_rng(5)
@@ -304,7 +306,7 @@ def test_shadow_walk_uses_wide_records_for_reference_trees_and_binary_walk_other
             nodes["aabb_min"][l] -= np.float32(0.37); nodes["aabb_max"][l + 1] += np.float32(0.21)
         b.nodes = nodes
     r2 = api.Renderer(sc2)
-    assert all(r2.debug_blas_wide(i) == -1 for i in range(len(sc2.blas)))
+    assert all(r2.debug_blas_wide(i) == -1 and r2.debug_blas_wide_closest(i) == -1 for i in range(len(sc2.blas)))
     ref = orc.OracleScene(sc2).render(threads=8)
     for mode in ({}, {"serial": True}, {"lane_trace": True}):
         out = r2.render(**mode)
@@ -344,14 +346,18 @@ def test_split_shadow_walk_changes_nothing(api, name, split, monkeypatch):
 
 
 @pytest.mark.parametrize("knobs", [{"RTX_FUSE_SHADE": "1"}, {"RTX_PK_CLOSEST_ASM": "0", "RTX_PK_DEFER_PRIMARY": "8"}, {"RTX_PK_DEFER_PRIMARY": "64"},
-                                   {"RTX_PK_DEFER_PRIMARY": "1", "RTX_PK_DEFER_CLOSEST": "2"}, {"RTX_PK_DEFER_PRIMARY": "16", "RTX_PK_DEFER_CLOSEST": "16", "RTX_LANE_FROM_LEVEL": "99"}],
-                         ids=["fused_shade", "compiled_shared_walk", "all_private", "share_everything", "share_all_levels_packets_everywhere"])
+                                   {"RTX_PK_DEFER_PRIMARY": "1", "RTX_PK_DEFER_CLOSEST": "2"}, {"RTX_PK_DEFER_PRIMARY": "16", "RTX_PK_DEFER_CLOSEST": "16", "RTX_LANE_FROM_LEVEL": "99"},
+                                   {"RTX_PK_WIDE_CLOSEST": "0"}, {"RTX_PK_WIDE_CLOSEST": "0", "RTX_PK_DEFER_PRIMARY": "64", "RTX_LANE_FROM_LEVEL": "99"},
+                                   {"RTX_PK_CLOSEST_ASM": "0", "RTX_PK_DEFER_PRIMARY": "8", "RTX_PK_WIDE_CLOSEST": "0"}],
+                         ids=["fused_shade", "compiled_shared_walk", "all_private", "share_everything", "share_all_levels_packets_everywhere",
+                              "binary_private_walk", "binary_private_walk_all_private_packets_everywhere", "compiled_shared_walk_binary_private_walk"])
 @pytest.mark.parametrize("name", ["materials_aniso", "dynamic", "tori16", "materials_b5", "materials_naive"])
 def test_closest_hit_walk_variants_change_nothing(api, name, knobs, monkeypatch):
     """Round 3's closest-hit choices are scheduling decisions: the hand-scheduled shared walk (pk_blas_closest_asm) with any hand-over
     threshold, for primary packets only or for every level, the compiled shared walk it replaced (RTX_PK_CLOSEST_ASM=0), every lane private,
-    and the opt-in fused trace-and-shade kernel (RTX_FUSE_SHADE=1: child slots from wave-private chunks, unused slots marked as holding no
-    ray) — always the reference's frame and ray counts, in both launch shapes."""
+    the opt-in fused trace-and-shade kernel (RTX_FUSE_SHADE=1: child slots from wave-private chunks, unused slots marked as holding no
+    ray), and the private lanes' walk over the ordered 4-wide records (default) or the binary tree (RTX_PK_WIDE_CLOSEST=0) — always the
+    reference's frame and ray counts, in both launch shapes."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     sc, g = util.load_golden(name)

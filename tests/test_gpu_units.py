@@ -158,11 +158,11 @@ def test_cyclic_node_arrays_are_refused(api):
             api.Renderer(sc)
 
 
-@pytest.mark.parametrize("name,k", [("cube", 1), ("cube", 2), ("cube", 12), ("monkey_small", 300)])
+@pytest.mark.parametrize("name,k", [("cube", 1), ("cube", 2), ("cube", 12), ("monkey_small", 40), ("monkey_small", 300)])
 def test_single_leaf_mesh(api, name, k):
     """A mesh whose BVH is one leaf (the root IS the leaf, node_count 1): the packet walkers enter their leaf path straight from the
     instance entry, the 4-wide records are empty; a leaf of 300 triangles exceeds their packed entries, so that mesh keeps the binary
-    walk.  Frame == oracle in every launch shape."""
+    walk (the closest-hit per-lane walk's ordered records: from 16 triangles).  Frame == oracle in every launch shape."""
     import copy
     import orc
     sc, _ = util.load_golden(name)
@@ -177,6 +177,7 @@ def test_single_leaf_mesh(api, name, k):
     ref = orc.OracleScene(sc).render(threads=4)
     r = api.Renderer(sc)
     assert r.debug_blas_wide(0) == (0 if k < 256 else -1)
+    assert r.debug_blas_wide_closest(0) == (0 if k < 16 else -1)      # stack and work-list entries of the closest-hit walk pack leaves of up to 15 triangles
     for mode in ({}, {"serial": True}, {"lane_trace": True}, {"packet_closest": True}):
         out = r.render(**mode)
         assert out["stats"] == ref["stats"], mode
