@@ -243,7 +243,8 @@ def build_roofline(args, sc, work, stats, level0_rays, kern, alone, ms_per_step,
             if ceil:       # the per-lane walk's other bound: divergent 64-byte gathers through the vector memory path (experiments/gather_occupancy)
                 recs = work["blas_nodes_closest"] / 2 + work["tri_tests_closest"] + work["instances_closest"]
                 pk["k_trace_closest"]["gather"] = {"bound": "divergent 64-byte gathers", "records_per_frame": int(recs), "G_records_per_s": round(recs / t * 1e-9, 1),
-                                                   "ceiling_G_records_per_s": ceil, "frac": round(recs / t * 1e-9 / ceil, 3), "ceiling_source": os.path.relpath(gfiles[-1], REPO)}
+                                                   "ceiling_G_records_per_s": ceil, "frac": round(recs / t * 1e-9 / ceil, 3), "ceiling_source": os.path.relpath(gfiles[-1], REPO),
+                                                   "records": "ALGORITHMIC: the child pairs, triangles and instance entries of the reference's binary walk (instrumented pass); the kernel's private lanes fetch ordered 4-wide records, i.e. fewer and larger ones, so this fraction compares the work done with what a binary per-lane walk could reach and may exceed 1"}
         if any_ms:
             pk["k_trace_any"] = {"bound": "valu", "includes": "k_trace_items (the launch that walks the items the packet launch hands over)", "ms_per_frame_alone": round(any_ms, 4),
                                  "units_per_frame": int(units["k_trace_any"]), "frac": round(units["k_trace_any"] / (any_ms * 1e-3) * 1e-9 / slab_peak, 4)}
