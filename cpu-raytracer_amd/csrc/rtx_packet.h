@@ -144,7 +144,7 @@ struct PkWalk {                      // everything a packet walk carries; wave-u
 #endif
 #ifdef RTX_LANE_PROF
     // closest-hit per-lane phase of ONE level (RTX_LANE_PROF_LEVEL): where do the dependent steps' microseconds go?  (tools/lane_prof.py)
-    uint32_t lp[16];                  // (kept wave-uniform in SGPRs: every update goes through readfirstlane) 0 phase ticks, 1 iterations, 2 inner steps, 3 leaf steps, 4 pops with a node fetch, 5 work-list reads, 6 triangle round trips,
+    uint32_t lp[16];                  // (kept wave-uniform in SGPRs: every update goes through readfirstlane) 0 phase ticks, 1 iterations, 2 inner steps, 3 leaf steps, 4 pops with a node fetch, 5 work-list reads, 6 lanes still walking summed over the iterations,
                                       // 7 ticks waiting for child pairs, 8 for triangles, 9 for pop / work-list fetches, 10 max phase ticks, 11 max iterations, 12 phases
 #endif
 };
@@ -1094,6 +1094,7 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
         if (__ballot(have_cur || sp > 0 || fi < fifo_n) == 0ull) break;
 #ifdef RTX_LANE_PROF
         lp_it++;
+        W.lp[6] = (uint32_t)rfl((int)(W.lp[6] + (uint32_t)__popcll(__ballot(have_cur || sp > 0 || fi < fifo_n))));      // lanes still walking in this iteration
         const bool lp_inner = __ballot(have_cur && (cur_cnt & 0x3fffffff) == 0) != 0ull;
         const unsigned long long lp_a = LP_NOW();
 #endif

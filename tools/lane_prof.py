@@ -22,6 +22,7 @@ print(f"  longest wave lifetime {raw[13] * tick:.1f} us, mean {raw[14] / max(raw
 print(f"  longest phase {raw[10] * tick:.1f} us with at most {raw[11]} iterations; mean phase {raw[0] / max(raw[12], 1) * tick:.1f} us, {raw[1] / max(raw[12], 1):.1f} iterations")
 print(f"  per iteration: {raw[0] / max(raw[1], 1) * tick:.3f} us;  longest phase / its iterations ~ {raw[10] / max(raw[11], 1) * tick:.3f} us")
 it = max(raw[1], 1)
+print(f"  lanes still walking per iteration: {raw[6] / it:.1f} of 64 ({raw[6] / it / 64:.2f}); lane-iterations per phase {raw[6] / max(raw[12], 1):.0f}")
 print(f"  iterations with an inner step {raw[2] / it:.2f}, with a leaf {raw[3] / it:.2f}, with a stack pop {raw[4] / it:.2f}, with a work-list read {raw[5] / it:.2f}")
 print(f"  ticks: child-pair fetch wait {raw[7] / max(raw[0], 1):.2f} of the phase ({raw[7] / max(raw[2], 1) * tick:.3f} us per inner step), "
       f"leaf (fetch + test, serial per triangle) {raw[8] / max(raw[0], 1):.2f} ({raw[8] / max(raw[3], 1) * tick:.3f} us per leaf step), "
