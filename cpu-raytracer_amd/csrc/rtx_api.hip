@@ -375,7 +375,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     c->q.pk_closest_asm = (int)knob_int("RTX_PK_CLOSEST_ASM", 1, 0, 1);
     c->q.pk_defer_t0_primary = (int)knob_int("RTX_PK_DEFER_PRIMARY", c->q.pk_closest_asm ? 4 : 64, 0, 64);
     c->q.pk_order = (int)knob_int("RTX_PK_ORDER", 1, 0, 1);
-    c->q.prof_level = (int)knob_int("RTX_LANE_PROF_LEVEL", 2, 0, RTX_MAX_LEVELS);      // -DRTX_LANE_PROF builds only (tools/lane_prof.py)
+    c->q.prof_level = (int)knob_int("RTX_LANE_PROF_LEVEL", 2, 0, 100 + RTX_MAX_LEVELS);      // -DRTX_LANE_PROF builds only (tools/lane_prof.py)
     c->q.pk_defer_grow = (int)knob_int("RTX_PK_GROW", 3, 0, 31);
     c->q.spill_threads = (int)max_threads;
     rc = ensure(c, c->d_spill, (size_t)c->q.spill_threads * (RTX_MAX_STACK - RTX_LDS_STACK) * 4 * 3);   // three regions, see k_trace_fast
@@ -456,7 +456,19 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
     const bool wide = !c->knobs.no_wide && build_nodes_pk4(nodes, node_count, triangle_count, nd4, &need4, c->knobs.pk4_order) && need4 <= RTX_PK4_MAX_NEED;
     std::vector<float4> nd4c; int need4c = 0;
     const bool wide_closest = !c->knobs.no_wide_closest && build_nodes_pk4c(nodes, node_count, triangle_count, nd4c, &need4c) && need4c <= RTX_MAX_STACK - 2;
-    void * dn = nullptr, * dt = nullptr, * dc = nullptr, * dnp = nullptr, * dn4 = nullptr, * dn4c = nullptr;
+    // the distinct box-plane coordinates per axis, ascending: a ray with a zero direction component can only produce a NaN in a slab test
+    // (0 * inf) if its origin lies exactly on one of them (pk_nan_possible, rtx_packet.h)
+    std::vector<float> planes[3];
+    for (int a = 0; a < 3; a++) {
+        planes[a].reserve((size_t)node_count * 2);
+        for (int i = 0; i < node_count; i++) { planes[a].push_back(nodes[i].aabb_min[a]); planes[a].push_back(nodes[i].aabb_max[a]); }
+        planes[a].erase(std::remove_if(planes[a].begin(), planes[a].end(), [](float v) { return v != v; }), planes[a].end());
+        std::sort(planes[a].begin(), planes[a].end());
+        planes[a].erase(std::unique(planes[a].begin(), planes[a].end()), planes[a].end());      // +0 and -0 compare equal: one entry
+        if (planes[a].empty()) planes[a].push_back(INFINITY);
+    }
+    void * dn = nullptr, * dt = nullptr, * dc = nullptr, * dnp = nullptr, * dn4 = nullptr, * dn4c = nullptr, * dpl[3] = { nullptr, nullptr, nullptr };
+    for (int a = 0; a < 3; a++) { HIP_OK(c, hipMalloc(&dpl[a], planes[a].size() * 4)); c->blas_allocs[blas_id].push_back(dpl[a]); HIP_OK(c, hipMemcpy(dpl[a], planes[a].data(), planes[a].size() * 4, hipMemcpyHostToDevice)); }
     if (wide_closest) { HIP_OK(c, hipMalloc(&dn4c, nd4c.size() * 16)); c->blas_allocs[blas_id].push_back(dn4c); HIP_OK(c, hipMemcpy(dn4c, nd4c.data(), nd4c.size() * 16, hipMemcpyHostToDevice)); }
     if (wide) { HIP_OK(c, hipMalloc(&dn4, nd4.size() * 16)); c->blas_allocs[blas_id].push_back(dn4); HIP_OK(c, hipMemcpy(dn4, nd4.data(), nd4.size() * 16, hipMemcpyHostToDevice)); }
     HIP_OK(c, hipMalloc(&dn, nd.size() * 16)); c->blas_allocs[blas_id].push_back(dn);
@@ -478,6 +490,7 @@ extern "C" int rtx_upload_blas(rtx_ctx * c, int32_t blas_id, const rtx_bvh_node 
     DevBlas & B = c->h_blas[blas_id];
     B.nodes = (const float4 *)dn; B.pk_nodes = (const float4 *)dnp; B.tri_hot = (const float4 *)dt; B.tri_cold = (const rtx_triangle_cold *)dc;
     B.pk4_nodes = (const float4 *)dn4; B.pk4c_nodes = (const float4 *)dn4c;
+    for (int a = 0; a < 3; a++) { B.planes[a] = (const float *)dpl[a]; B.plane_count[a] = (int32_t)planes[a].size(); }
     B.node_count = node_count; B.tri_count = triangle_count; B.material_offset = material_offset; B.pk4_need = wide ? need4 : -1; B.pk4c_need = wide_closest ? need4c : -1;
     return upload(c, c->d_blas, c->h_blas.data(), c->h_blas.size() * sizeof(DevBlas));
 }

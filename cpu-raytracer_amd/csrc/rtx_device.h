@@ -55,7 +55,8 @@ struct DevBlas {
     const rtx_triangle_cold * tri_cold;   // reference layout, 64 B
     const float4 *            pk4_nodes;  // 4-wide records for the shadow-ray packet walk (128 B at 64 * left-child index), or null: tree not nested / too big
     const float4 *            pk4c_nodes; // ordered 4-wide records for the closest-hit per-lane walk (build_nodes_pk4c, rtx_api.hip), or null
-    int32_t node_count, tri_count, material_offset, pk4_need, pk4c_need, pad_;
+    const float *             planes[3];  // per axis: the distinct box-plane coordinates of the tree's nodes, ascending (plane_member, rtx_packet.h)
+    int32_t node_count, tri_count, material_offset, pk4_need, pk4c_need, plane_count[3];
 };
 
 struct DevTexture {

@@ -1239,6 +1239,40 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
     W.fifo_n = 0;
 }
 
+// ---- which rays need the reference-form slab test ---------------------------------------------------------------------------------------
+// The fast forms (hardware min / max, the sign-coherent test, the nesting arguments of the 4-wide records) equal the reference's `a < b ? a : b`
+// forms as long as no slab test produces a NaN, and the only NaN a slab test can produce is 0 * inf: an infinite inverse-direction component
+// (a direction component of +-0, or so small that its reciprocal overflows) times a box plane that passes exactly through the ray's origin on that
+// axis.  A zero component alone is harmless — (b - o) * inf is +-inf, ordered like any other value, and AABB::intersect's comparisons see no
+// difference — and common: the middle row of pixels of any camera that is only rotated about y has d.y == 0.  So a ray is sent to the
+// reference-form walker only if, on an axis with a non-finite inverse, its origin equals one of the tree's box-plane coordinates (the distinct
+// values per axis, sorted at upload: a binary search by the few lanes concerned).
+RTX_D bool plane_member(const float * __restrict__ planes, const int n, const float x) {
+    if (x != x) return true;
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (planes[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo < n && planes[lo] == x;
+}
+RTX_D bool pk_nan_possible(const DevBlas & B, const v3 o, const v3 inv) {
+    bool r = false;
+    if (!(__builtin_fabsf(inv.x) < INFINITY)) r |= (inv.x != inv.x) || plane_member(B.planes[0], B.plane_count[0], o.x);
+    if (!(__builtin_fabsf(inv.y) < INFINITY)) r |= (inv.y != inv.y) || plane_member(B.planes[1], B.plane_count[1], o.y);
+    if (!(__builtin_fabsf(inv.z) < INFINITY)) r |= (inv.z != inv.z) || plane_member(B.planes[2], B.plane_count[2], o.z);
+    return r;
+}
+// the same question for the TLAS (a handful of nodes, rebuilt every frame: its planes are compared one by one; a large TLAS is not searched)
+RTX_D bool pk_nan_possible_tlas(const DevScene & sc, const v3 o, const v3 inv) {
+    const bool ix = !(__builtin_fabsf(inv.x) < INFINITY), iy = !(__builtin_fabsf(inv.y) < INFINITY), iz = !(__builtin_fabsf(inv.z) < INFINITY);
+    if (!(ix | iy | iz)) return false;
+    if (sc.tlas_node_count > 128 || inv.x != inv.x || inv.y != inv.y || inv.z != inv.z || o.x != o.x || o.y != o.y || o.z != o.z) return true;
+    bool r = false;
+    for (int i = 0; i < sc.tlas_node_count; i++) {
+        const float4 a = sc.tlas_nodes[2 * i], b = sc.tlas_nodes[2 * i + 1];          // (min.xyz, -) (max.xyz, -)
+        r |= (ix & ((a.x == o.x) | (b.x == o.x))) | (iy & ((a.y == o.y) | (b.y == o.y))) | (iz & ((a.z == o.z) | (b.z == o.z)));
+    }
+    return r;
+}
+
 // ---- the whole closest-hit walk of one BLAS for the lanes that walk TOGETHER, hand-scheduled -------------------------------------------
 // BottomLevelBVH::trace (BottomLevelBVH.cpp:355-396) for the lanes of W.m from the node in W.cur_*, until the packet stack is back at
 // W.floor_sp: ordered descend with sign split (the asm of pk_descend), leaves (triangle_trace's hit test with the triangle in SGPRs,
@@ -1702,7 +1736,7 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
             W.lane_nodes = RTX_GPTR(B.nodes); W.lane_tris = RTX_GPTR(B.tri_hot); if (!ANY) W.lane_nodes4c = RTX_GPTR(B.pk4c_nodes);
             W.floor_sp = W.sp; W.depth = 0;
             const float4 na = sld(W.nodes, 0), nb = sld(W.nodes, 1);            // BLAS root (BottomLevelBVH.cpp:360-370)
-            const bool risky = FAST && __ballot(W.valid && !inv_is_finite(cinv)) != 0ull;
+            const bool risky = FAST && __ballot(W.valid && !inv_is_finite(cinv) && pk_nan_possible(B, co, cinv)) != 0ull;
             W.m = (risky ? __ballot(pk_slab<false>(na, nb, W.ray)) : __ballot(pk_slab<FAST>(na, nb, W.ray))) & pm;
             W.cur_idx = 0; W.cur_first = as_i(nb.z); W.cur_cnt = as_i(nb.w);
             if (risky) return false;
@@ -1712,7 +1746,11 @@ RTX_D bool pk_walk(const DevScene & sc, PkWalk & W, const int lane, const bool o
 #ifdef RTX_LANE_PROF
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long sw_t0 = __builtin_amdgcn_s_memtime(); const int sw_s0 = W.pk_steps;
 #endif
+#ifdef RTX_PK_SKIPWALK
+                W.m = 0ull;                                          // measurement only: everything but the BLAS walk
+#else
                 pk_blas_closest_asm(W, sc.stack_size, ordered ? 1 : 0, H, PRIM_TRI | inst, H.gthread);
+#endif
 #ifdef RTX_LANE_PROF
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 W.lp[13] = (uint32_t)rfl((int)(W.lp[13] + (uint32_t)(__builtin_amdgcn_s_memtime() - sw_t0))); W.lp[14] = (uint32_t)rfl((int)(W.lp[14] + (uint32_t)(W.pk_steps - sw_s0)));
@@ -1803,7 +1841,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
 #endif
 #ifdef RTX_LANE_PROF
     for (int i = 0; i < 16; i++) W.lp[i] = 0u;
-    const unsigned long long lp_k0 = __builtin_amdgcn_s_memtime(), lp_r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long lp_k0 = __builtin_amdgcn_s_memtime(), lp_r0 = __builtin_amdgcn_s_memrealtime(); bool lp_had_packet = false;
 #endif
     W.tlas = pk_cptr(sc.pk_tlas_nodes);
     W.err = 0; W.st_pairs = W.st_tris = W.st_pair_lanes = W.st_tri_lanes = 0ull; W.item_n = 0; W.item_slot = 0; W.cur_blas = 0;
@@ -1855,6 +1893,9 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
             if (!got) break;
         }
 
+#ifdef RTX_LANE_PROF
+        lp_had_packet = true;
+#endif
         // shadow-ray launches walk their packets last level first: the packets of the deeper levels are the incoherent, expensive ones
         // (longest jobs first: 0.79 -> 0.73 ms for the merged launch); RTX_PK_ORDER=0 restores queue order
         if (ANY && q.pk_order != 0) pk = npk - 1u - pk;
@@ -1925,7 +1966,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
         if (W.alive != 0ull && sc.tlas_node_count > 0) {
             const v3 winv = vrcp(wd);
             pk_set_ray(W.ray, wo, wd, winv);
-            const bool nanfree_world = __ballot(W.valid && !inv_is_finite(winv)) == 0ull;
+            const bool nanfree_world = __ballot(W.valid && !inv_is_finite(winv) && pk_nan_possible_tlas(sc, wo, winv)) == 0ull;
             W.nodes = W.tlas; W.tris = W.tlas;
             W.sp = 0; W.floor_sp = -1; W.cur_inst = 0; W.depth = 0; W.cur_idx = 0;
             {   // TLAS root: pushed, popped and tested by the reference (TopLevelBVH.cpp:58-67)
@@ -1938,7 +1979,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
             const unsigned long long pk_w0_ = __builtin_amdgcn_s_memtime();
 #endif
             bool done = false;
-            if (nanfree_world) done = pk_walk<ANY, PSTAT, true, !PSTAT, SPLIT>(sc, W, lane, ordered, H, world);
+            if (nanfree_world && !done) done = pk_walk<ANY, PSTAT, true, !PSTAT, SPLIT>(sc, W, lane, ordered, H, world);
             if (!done) pk_walk<ANY, PSTAT, false, false, SPLIT>(sc, W, lane, ordered, H, world);
 #ifdef RTX_PK_PROF
             {   // slot 4: the longest single packet walk (max), slot 9: walks longer than 2^18 ticks
@@ -1984,7 +2025,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
     if (lane == 0) for (int i = 0; i < 10; i++) { if (i == 4 || i == 5 || i == 7 || i == 8 || i == 9) atomicMax(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); else atomicAdd(&ctr->work[(ANY ? 0 : 10) + i], W.prof[i]); }
 #endif
 #ifdef RTX_LANE_PROF
-    if (!ANY && level == q.prof_level && lane == 0 && W.lp[12] > 0u) {       // waves that walked something (no atomic storm of the idle ones)
+    if (!ANY && level == q.prof_level % 100 && lane == 0 && (W.lp[12] > 0u || (q.prof_level >= 100 && lp_had_packet))) {       // waves that walked something (no atomic storm of the idle ones); + 100: every wave that had a packet
         // wave-uniform values; inner-wait ticks were accumulated by every lane identically
         for (int i = 0; i < 10; i++) atomicAdd(&ctr->work[i], (unsigned long long)W.lp[i]);
         atomicMax(&ctr->work[10], (unsigned long long)W.lp[10]); atomicMax(&ctr->work[11], (unsigned long long)W.lp[11]); atomicAdd(&ctr->work[12], (unsigned long long)W.lp[12]);

@@ -265,3 +265,24 @@ def test_chain_shaped_tlas_takes_the_per_lane_kernels_instead_of_overflowing_the
     for mode in ({}, {"serial": True}, {"packet_closest": True}):
         out = r.render(**mode)
         assert out["stats"] == ref["stats"] and np.array_equal(out["rgb"].view(np.uint32), ref["rgb"].view(np.uint32)), (n, mode)
+
+
+@pytest.mark.parametrize("cam_y", ["1", "1.25", "-1", "0"])
+@pytest.mark.parametrize("mesh", ["Cube", "Torus"])
+def test_zero_direction_components_on_and_off_box_planes(api, mesh, cam_y):
+    """A camera that is only translated has d.y == 0 on its middle row and d.x == 0 on its middle column: inverse components of +-inf.  The slab
+    test then yields a NaN (0 * inf) only where the ray's origin lies exactly on a box plane of that axis; only those rays need the reference-form
+    walker (csrc/rtx_packet.h pk_nan_possible: a search of the tree's distinct plane coordinates), all others — the common case — stay on the fast
+    paths.  Camera heights on (1, -1: Cube.obj's faces; 0: planes of either tree) and off (1.25) the planes; frame == oracle in every launch shape."""
+    import orc
+    from pyrtx import assemble
+    text = (f"size 64 48\nbounces 2\nmesh ./Data/{mesh}.obj 0 0 0\nmatset mesh:0:0 reflection 0.5 0.5 0.5\nplane 0 -1.5 0\n"
+            f"point 20 20 20 0 {cam_y} -3\ndir 0.5 0.5 0.5 0 -1 0\ncamera 0 {cam_y} -4 0 0 0 1\n")
+    sc = assemble.scene_from_script(text, os.path.join(util.GOLDEN, "meshes"), accel="sbvh")
+    ref = orc.OracleScene(sc).render(threads=8)
+    r = api.Renderer(sc)
+    for mode in ({}, {"serial": True}, {"lane_trace": True}, {"packet_closest": True}, {"simple_trace": True}):
+        out = r.render(**mode)
+        assert out["stats"] == ref["stats"], mode
+        assert np.array_equal(np.isnan(out["rgb"]), np.isnan(ref["rgb"])), mode
+        assert util.bit_exact(out["rgb"], ref["rgb"]) and np.array_equal(out["packed"], ref["packed"]), mode

@@ -6,6 +6,8 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(REPO, "cpu-raytracer_amd"))
 from pyrtx import api, host
 sc = host.atrium_scene(1920, 1080, 3, detail=1)
+if os.environ.get("PERLEVEL_CAM_Y"):      # A/B: the camera off the tree's box planes (its default height 5.5 IS a plane of the atrium's tree: the middle row of pixels takes the reference-form walker)
+    sc.camera = host.camera_basis(1920, 1080, float(np.deg2rad(110.0)), (host.ATRIUM_CAMERA[0][0], float(os.environ["PERLEVEL_CAM_Y"]), host.ATRIUM_CAMERA[0][2]), host.axis_angle(*host.ATRIUM_CAMERA[1]))
 r = api.Renderer(sc)
 for shard in (1, 8):
     n = (sc.tile_count + shard - 1) // shard

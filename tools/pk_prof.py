@@ -7,7 +7,9 @@ from pyrtx.ctypes_structs import RtxStats, RtxWork
 bounces = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 sc = host.atrium_scene(1920, 1080, bounces)
 r = api.Renderer(sc)
-for _ in range(2): r.render_async(serial=True)
+shard = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # 1/shard of the tiles (tile t with t % shard == 0)
+n_tiles = (sc.tile_count + shard - 1) // shard
+for _ in range(2): r.render_async(0, shard, n_tiles, serial=True)
 r.synchronize()
 st, wk = RtxStats(), RtxWork()
 r.lib.rtx_get_stats(r.ctx, C.byref(st), C.byref(wk))
