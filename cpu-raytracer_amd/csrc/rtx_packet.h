@@ -1239,40 +1239,6 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
     W.fifo_n = 0;
 }
 
-// ---- which rays need the reference-form slab test ---------------------------------------------------------------------------------------
-// The fast forms (hardware min / max, the sign-coherent test, the nesting arguments of the 4-wide records) equal the reference's `a < b ? a : b`
-// forms as long as no slab test produces a NaN, and the only NaN a slab test can produce is 0 * inf: an infinite inverse-direction component
-// (a direction component of +-0, or so small that its reciprocal overflows) times a box plane that passes exactly through the ray's origin on that
-// axis.  A zero component alone is harmless — (b - o) * inf is +-inf, ordered like any other value, and AABB::intersect's comparisons see no
-// difference — and common: the middle row of pixels of any camera that is only rotated about y has d.y == 0.  So a ray is sent to the
-// reference-form walker only if, on an axis with a non-finite inverse, its origin equals one of the tree's box-plane coordinates (the distinct
-// values per axis, sorted at upload: a binary search by the few lanes concerned).
-RTX_D bool plane_member(const float * __restrict__ planes, const int n, const float x) {
-    if (x != x) return true;
-    int lo = 0, hi = n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (planes[mid] < x) lo = mid + 1; else hi = mid; }
-    return lo < n && planes[lo] == x;
-}
-RTX_D bool pk_nan_possible(const DevBlas & B, const v3 o, const v3 inv) {
-    bool r = false;
-    if (!(__builtin_fabsf(inv.x) < INFINITY)) r |= (inv.x != inv.x) || plane_member(B.planes[0], B.plane_count[0], o.x);
-    if (!(__builtin_fabsf(inv.y) < INFINITY)) r |= (inv.y != inv.y) || plane_member(B.planes[1], B.plane_count[1], o.y);
-    if (!(__builtin_fabsf(inv.z) < INFINITY)) r |= (inv.z != inv.z) || plane_member(B.planes[2], B.plane_count[2], o.z);
-    return r;
-}
-// the same question for the TLAS (a handful of nodes, rebuilt every frame: its planes are compared one by one; a large TLAS is not searched)
-RTX_D bool pk_nan_possible_tlas(const DevScene & sc, const v3 o, const v3 inv) {
-    const bool ix = !(__builtin_fabsf(inv.x) < INFINITY), iy = !(__builtin_fabsf(inv.y) < INFINITY), iz = !(__builtin_fabsf(inv.z) < INFINITY);
-    if (!(ix | iy | iz)) return false;
-    if (sc.tlas_node_count > 128 || inv.x != inv.x || inv.y != inv.y || inv.z != inv.z || o.x != o.x || o.y != o.y || o.z != o.z) return true;
-    bool r = false;
-    for (int i = 0; i < sc.tlas_node_count; i++) {
-        const float4 a = sc.tlas_nodes[2 * i], b = sc.tlas_nodes[2 * i + 1];          // (min.xyz, -) (max.xyz, -)
-        r |= (ix & ((a.x == o.x) | (b.x == o.x))) | (iy & ((a.y == o.y) | (b.y == o.y))) | (iz & ((a.z == o.z) | (b.z == o.z)));
-    }
-    return r;
-}
-
 // ---- the whole closest-hit walk of one BLAS for the lanes that walk TOGETHER, hand-scheduled -------------------------------------------
 // BottomLevelBVH::trace (BottomLevelBVH.cpp:355-396) for the lanes of W.m from the node in W.cur_*, until the packet stack is back at
 // W.floor_sp: ordered descend with sign split (the asm of pk_descend), leaves (triangle_trace's hit test with the triangle in SGPRs,

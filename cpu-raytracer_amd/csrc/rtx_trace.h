@@ -136,6 +136,41 @@ RTX_D bool inv_is_finite(v3 inv) {
     return (__builtin_fabsf(inv.x) < INFINITY) & (__builtin_fabsf(inv.y) < INFINITY) & (__builtin_fabsf(inv.z) < INFINITY);   // false for inf and NaN
 }
 
+// ---- which rays need the reference-form slab test ---------------------------------------------------------------------------------------
+// The fast forms (hardware min / max, the sign-coherent test, the nesting arguments of the 4-wide records) equal the reference's `a < b ? a : b`
+// forms as long as no slab test produces a NaN, and the only NaN a slab test can produce is 0 * inf: an infinite inverse-direction component
+// (a direction component of +-0, or so small that its reciprocal overflows) times a box plane that passes exactly through the ray's origin on that
+// axis.  A zero component alone is harmless — (b - o) * inf is +-inf, ordered like any other value, and AABB::intersect's comparisons see no
+// difference — and common: the middle row of pixels of any camera that is only rotated about y has d.y == 0.  So a ray is sent to the
+// reference-form walker only if, on an axis with a non-finite inverse, its origin equals one of the tree's box-plane coordinates (the distinct
+// values per axis, sorted at upload: a binary search by the few lanes concerned).
+RTX_D bool plane_member(const float * __restrict__ planes, const int n, const float x) {
+    if (x != x) return true;
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (planes[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo < n && planes[lo] == x;
+}
+RTX_D bool pk_nan_possible(const DevBlas & B, const v3 o, const v3 inv) {
+    bool r = false;
+    if (!(__builtin_fabsf(inv.x) < INFINITY)) r |= (inv.x != inv.x) || plane_member(B.planes[0], B.plane_count[0], o.x);
+    if (!(__builtin_fabsf(inv.y) < INFINITY)) r |= (inv.y != inv.y) || plane_member(B.planes[1], B.plane_count[1], o.y);
+    if (!(__builtin_fabsf(inv.z) < INFINITY)) r |= (inv.z != inv.z) || plane_member(B.planes[2], B.plane_count[2], o.z);
+    return r;
+}
+// the same question for the TLAS (a handful of nodes, rebuilt every frame: its planes are compared one by one; a large TLAS is not searched)
+RTX_D bool pk_nan_possible_tlas(const DevScene & sc, const v3 o, const v3 inv) {
+    const bool ix = !(__builtin_fabsf(inv.x) < INFINITY), iy = !(__builtin_fabsf(inv.y) < INFINITY), iz = !(__builtin_fabsf(inv.z) < INFINITY);
+    if (!(ix | iy | iz)) return false;
+    if (sc.tlas_node_count > 128 || inv.x != inv.x || inv.y != inv.y || inv.z != inv.z || o.x != o.x || o.y != o.y || o.z != o.z) return true;
+    bool r = false;
+    for (int i = 0; i < sc.tlas_node_count; i++) {
+        const float4 a = sc.tlas_nodes[2 * i], b = sc.tlas_nodes[2 * i + 1];          // (min.xyz, -) (max.xyz, -)
+        r |= (ix & ((a.x == o.x) | (b.x == o.x))) | (iy & ((a.y == o.y) | (b.y == o.y))) | (iz & ((a.z == o.z) | (b.z == o.z)));
+    }
+    return r;
+}
+
+
 // Sphere::trace hit test only (Sphere.cpp:9-42); attributes are rebuilt in the shade kernel
 RTX_D bool sphere_closest(const rtx_sphere & sp, v3 o, v3 d, float tbest, float & t_out) {
     v3 oc = vsub(o, v3p(sp.center));
@@ -459,7 +494,7 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
     uint32_t * const head = ANY ? &ctr->fetch_any[level] : &ctr->fetch_closest[level];
     const bool ordered = sc.traversal_strategy == RTX_TRAVERSE_ORDERED;
 
-    bool has_ray = false, have_cur = false, lane_risky = false;   // lane_risky: cinv has an infinite / NaN component
+    bool has_ray = false, have_cur = false, lane_risky = false, risky_world = false;   // lane_risky: a slab test of this ray in the space it is traversing can produce a NaN (pk_nan_possible)
     uint32_t out_slot = 0;
     v3 wo = V3(0, 0, 0), wd = wo, winv = wo, co = wo, cd = wo, cinv = wo;
     float tcur = 0.0f;
@@ -549,7 +584,7 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
                         q.socc[out_slot] = 1u;
                     } else if (sc.tlas_node_count > 0) {
                         winv = vrcp(wd);
-                        co = wo; cd = wd; cinv = winv; lane_risky = !inv_is_finite(cinv);
+                        co = wo; cd = wd; cinv = winv; risky_world = !inv_is_finite(winv) && pk_nan_possible_tlas(sc, wo, winv); lane_risky = risky_world;
                         cur_nodes = RTX_GPTR(sc.tlas_nodes); floor_sp = -1; sp = 0;
                         has_ray = true;
                         // TLAS root: pushed, popped and tested by the reference (TopLevelBVH.cpp:58-67)
@@ -641,7 +676,7 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
             }
             // ---- C: pop ----
             if (has_ray && !have_cur) {
-                if (floor_sp >= 0 && sp == floor_sp) { floor_sp = -1; co = wo; cd = wd; cinv = winv; cur_nodes = RTX_GPTR(sc.tlas_nodes); lane_risky = !inv_is_finite(cinv); }
+                if (floor_sp >= 0 && sp == floor_sp) { floor_sp = -1; co = wo; cd = wd; cinv = winv; cur_nodes = RTX_GPTR(sc.tlas_nodes); lane_risky = risky_world; }
                 if (sp == 0) { finish(); continue; }
                 float key = 0.0f;
                 const int e = pop(key);
@@ -650,8 +685,9 @@ void k_trace_fast(const DevScene sc, const DevQueues q, const int level, const i
                     const rtx_instance & I = sc.instances[inst];
                     co = xform_pos(I.world_inv, wo);
                     cd = xform_dir(I.world_inv, wd);
-                    cinv = vrcp(cd); lane_risky = !inv_is_finite(cinv);
+                    cinv = vrcp(cd);
                     const DevBlas & B = sc.blas[I.blas_id];
+                    lane_risky = !inv_is_finite(cinv) && pk_nan_possible(B, co, cinv);
                     cur_nodes = RTX_GPTR(B.nodes); cur_tris = RTX_GPTR(B.tri_hot); cur_inst = inst;
                     floor_sp = sp;
                     const float4 na = gld(cur_nodes, 0), nb = gld(cur_nodes, 1);    // BLAS root
