@@ -286,3 +286,55 @@ def test_zero_direction_components_on_and_off_box_planes(api, mesh, cam_y):
         assert out["stats"] == ref["stats"], mode
         assert np.array_equal(np.isnan(out["rgb"]), np.isnan(ref["rgb"])), mode
         assert util.bit_exact(out["rgb"], ref["rgb"]) and np.array_equal(out["packed"], ref["packed"]), mode
+
+
+@pytest.mark.parametrize("shape,n,ordered", [("chain", 20, 1), ("chain", 34, 0), ("chain", 60, 1), ("comb", 12, 1), ("comb", 24, 1)])
+def test_deep_degenerate_blas_stacks_of_the_closest_hit_walk(api, shape, n, ordered):
+    """Degenerate trees keep many entries pending on a lane's stack: past the 16 entries a lane holds in LDS the walk spills to HBM, with the
+    pop-time keys (csrc/rtx_packet.h pk_lane_phase_closest).  "chain": n triangles in a row, every inner node = one leaf + the rest (depth n - 1;
+    the ordered 4-wide records need about as many entries as the binary walk: 59 for n = 60).  "comb": every step = (leaf, leaf) + (leaf, rest):
+    four slots per record, three of them pending — 1.5 entries per level, so that 24 steps (depth 47, legal for BVH_TRAVERSAL_STACK_SIZE 64) would
+    need more than the 64-entry stack holds and the mesh keeps the binary walk (rtx_debug_blas_wide_closest == -1).  Frame == oracle in every
+    launch shape, reflective triangles so that the deeper levels walk the tree from the inside too."""
+    import copy
+    import orc
+    from pyrtx import scene_io as sio
+    sc, _ = util.load_golden("cube")
+    sc = copy.deepcopy(sc)
+    n_tri = n if shape == "chain" else 3 * n + 1
+    hot = np.zeros(n_tri, sio.TRI_HOT); cold = np.zeros(n_tri, sio.TRI_COLD)
+    rng = np.random.default_rng(n)
+    for i in range(n_tri):
+        z = float(rng.uniform(-0.5, 0.5))
+        hot["position_0"][i] = (i * 0.45 - n_tri * 0.225, -0.6, z); hot["position_edge_1"][i] = (0.4, 0.1 * (i % 3), 0.3 * ((i % 2) * 2 - 1)); hot["position_edge_2"][i] = (0.05, 1.2, 0.0)
+        cold["normal_0"][i] = (0, 0, -1); cold["material_id"][i] = sc.blas[0].tri_cold["material_id"][0]
+    # the tree as nested tuples over triangle indices in order, then laid out like the reference's builders: root 0, node 1 unused, children in pairs
+    def chain(i): return i if i == n_tri - 1 else (i, chain(i + 1))
+    def comb(i): return ((i, i + 1), (i + 2, comb(i + 3))) if i + 3 < n_tri else i
+    import sys
+    sys.setrecursionlimit(10000)
+    tree = chain(0) if shape == "chain" else comb(0)
+    nodes = np.zeros(2 * n_tri, sio.BVH_NODE)
+    next_pair = [2]
+    def place(t, idx):
+        if isinstance(t, int):
+            p = np.stack([hot["position_0"][t], hot["position_0"][t] + hot["position_edge_1"][t], hot["position_0"][t] + hot["position_edge_2"][t]]).astype(np.float32)
+            nodes[idx]["aabb_min"] = p.min(axis=0); nodes[idx]["aabb_max"] = p.max(axis=0); nodes[idx]["left_or_first"] = t; nodes[idx]["count"] = 1
+        else:
+            l = next_pair[0]; next_pair[0] += 2
+            place(t[0], l); place(t[1], l + 1)
+            nodes[idx]["aabb_min"] = np.minimum(nodes[l]["aabb_min"], nodes[l + 1]["aabb_min"]); nodes[idx]["aabb_max"] = np.maximum(nodes[l]["aabb_max"], nodes[l + 1]["aabb_max"])
+            nodes[idx]["left_or_first"] = l; nodes[idx]["count"] = 1 << 30          # split axis x
+    place(tree, 0)
+    sc.blas[0] = sio.Blas(nodes[:next_pair[0]].copy(), hot, cold, sc.blas[0].material_offset, 1)
+    sc.materials["reflection"][:] = 0.4
+    sc.config["traversal_strategy"] = ordered; sc.config["bounces"] = 2
+    ref = orc.OracleScene(sc).render(threads=8)
+    r = api.Renderer(sc)
+    need = r.debug_blas_wide_closest(0)
+    assert need == {("chain", 20): 19, ("chain", 34): 33, ("chain", 60): 59, ("comb", 12): 36, ("comb", 24): -1}[(shape, n)], need
+    for mode in ({}, {"serial": True}, {"lane_trace": True}, {"packet_closest": True}):
+        out = r.render(**mode)
+        assert out["stats"] == ref["stats"], mode
+        assert util.bit_exact(out["rgb"], ref["rgb"]) and np.array_equal(out["packed"], ref["packed"]), mode
+    assert int(ref["stats"]["reflection"]) > 0
