@@ -220,7 +220,7 @@ static bool build_nodes_pk4(const rtx_bvh_node * nodes, int n, int tri_count, st
 // grandchildren are taken in the order the two binary levels would take them: X's near child's near child first.  The record of inner node
 // j keeps the tree's shape for that: slots 0-1 = the left child's children (or the left child itself, a leaf, in slot 0), slots 2-3 the
 // right child's; the near / far axes of the two children ride in slots 0 and 2.  Half the dependent fetches per walk.
-//   record (128 B, at byte offset 64 * left-child index of j): 4 x { (min.xyz, first) (max.xyz, meta) },
+//   record (128 B, at byte offset 64 * left-child index of j): 4 x { (min.x, min.y, max.x, max.y) (min.z, max.z, first, meta) },
 //   meta = leaf count (< 16) | axis of the slot's PARENT (slots 0 and 2; 0: the parent is a leaf, i.e. the slot itself) << 26 | axis of the slot node << 30;
 //   unused slots hold a point box, which never passes.  *stack_need = pending entries a lane's walk can have (bound over all visiting orders).
 static bool build_nodes_pk4c(const rtx_bvh_node * nodes, int n, int tri_count, std::vector<float4> & out, int * stack_need) {
@@ -253,8 +253,8 @@ static bool build_nodes_pk4c(const rtx_bvh_node * nodes, int n, int tri_count, s
                 const rtx_bvh_node & sn = nodes[si];
                 const uint32_t meta = ((uint32_t)sn.count & 0x3fffffffu) | (t == 0 && !leaf ? (((uint32_t)c.count >> 30) << 26) : 0u) | (((uint32_t)sn.count >> 30) << 30);
                 float f, m; memcpy(&f, &sn.left_or_first, 4); memcpy(&m, &meta, 4);
-                rec[2 * (2 * g + t)]     = make_float4(sn.aabb_min[0], sn.aabb_min[1], sn.aabb_min[2], f);
-                rec[2 * (2 * g + t) + 1] = make_float4(sn.aabb_max[0], sn.aabb_max[1], sn.aabb_max[2], m);
+                rec[2 * (2 * g + t)]     = make_float4(sn.aabb_min[0], sn.aabb_min[1], sn.aabb_max[0], sn.aabb_max[1]);      // the packet kernels' slot layout: the slab test runs in packed fp32
+                rec[2 * (2 * g + t) + 1] = make_float4(sn.aabb_min[2], sn.aabb_max[2], f, m);
                 nd = std::max(nd, need[si]); ns++;
             }
         }

@@ -1104,10 +1104,20 @@ RTX_D void pk_lane_phase_closest(PkWalk & W, const int lane, const bool ordered,
             const float4 a0 = gld(nodes4, base), a1 = gld(nodes4, base + 1), b0 = gld(nodes4, base + 2), b1 = gld(nodes4, base + 3);
             const float4 c0 = gld(nodes4, base + 4), c1 = gld(nodes4, base + 5), d0 = gld(nodes4, base + 6), d1 = gld(nodes4, base + 7);
             float k0, k1, k2, k3;
-            const bool p0 = slab_test_sel<true>(a0, a1, co, cinv, tcur, k0), p1 = slab_test_sel<true>(b0, b1, co, cinv, tcur, k1);
-            const bool p2 = slab_test_sel<true>(c0, c1, co, cinv, tcur, k2), p3 = slab_test_sel<true>(d0, d1, co, cinv, tcur, k3);
+            // AABB::intersect on a slot (min.x, min.y, max.x, max.y) (min.z, max.z, -, -) in packed fp32 — the arithmetic of pk_slab<true>, the result of
+            // slab_test_sel<true>: passes, and t_near as the key of the pop-time test
+            auto slab = [&](const float4 & q0, const float4 & q1, float & key) {
+                const rtx_f2v t0xy = (rtx_f2v{ q0.x, q0.y } - W.ray.o_xy) * W.ray.i_xy;
+                const rtx_f2v t1xy = (rtx_f2v{ q0.z, q0.w } - W.ray.o_xy) * W.ray.i_xy;
+                const rtx_f2v tz   = (rtx_f2v{ q1.x, q1.y } - W.ray.o_zz) * W.ray.i_zz;
+                const float t_near = pk_max_s(RAY_EPSILON, pk_max3(pk_min(t0xy.x, t1xy.x), pk_min(t0xy.y, t1xy.y), pk_min(tz.x, tz.y)));
+                const float t_far  = pk_min(tcur, pk_min3(pk_max(t0xy.x, t1xy.x), pk_max(t0xy.y, t1xy.y), pk_max(tz.x, tz.y)));
+                key = t_near;
+                return t_near < t_far;
+            };
+            const bool p0 = slab(a0, a1, k0), p1 = slab(b0, b1, k1), p2 = slab(c0, c1, k2), p3 = slab(d0, d1, k3);
             // a slot as a stack entry: its node's own (first, count, axis); a key of +inf marks a slot that failed (or is unused)
-            auto entry = [](const float4 & lo, const float4 & hi) { const uint32_t m = (uint32_t)as_i(hi.w); return (int)(0x40000000u | ((m >> 30) << 28) | ((m & 15u) << 24) | (uint32_t)as_i(lo.w)); };
+            auto entry = [](const float4 & lo, const float4 & hi) { const uint32_t m = (uint32_t)as_i(hi.w); return (int)(0x40000000u | ((m >> 30) << 28) | ((m & 15u) << 24) | (uint32_t)as_i(hi.z)); };
             int e0 = entry(a0, a1), e1 = entry(b0, b1), e2 = entry(c0, c1), e3 = entry(d0, d1);
             k0 = p0 ? k0 : INFINITY; k1 = p1 ? k1 : INFINITY; k2 = p2 ? k2 : INFINITY; k3 = p3 ? k3 : INFINITY;
             // the lane's own near / far order at the node and at its two children (BVHNode.h:30-40); axis 0 = a leaf child: one slot, no order
