@@ -184,7 +184,8 @@ def build_roofline(args, sc, work, stats, level0_rays, kern, alone, ms_per_step,
     """ONE statement of where the frame stands against the chip:
       headline   whole-frame traversal arithmetic (the reference's own AABB::intersect + triangle-test calls for this frame's rays, triangle tests
                  priced in box tests) / ms_per_step of the timed region / the chip's rate for that arithmetic alone (experiments/slab_rate, run here);
-      kernel     the kernel with the most GPU time per step in the timed region (HIP events on its launch stream) is named as dominant;
+      kernel     the dominant kernel: the one whose launches need the most time per frame with the chip to themselves (serial-mode pass; without
+                 that pass: the most GPU time per step in the timed region, HIP events on its launch stream);
       per_kernel every frame kernel against ITS bound on ONE denominator: its launches' time per frame with nothing else on the chip
                  (the serial-mode pass after the timed region) — traversal kernels against the VALU ceiling (closest hit also against the
                  divergent-gather ceiling), k_shade / k_resolve against HBM bandwidth;
@@ -196,7 +197,12 @@ def build_roofline(args, sc, work, stats, level0_rays, kern, alone, ms_per_step,
     per_step = {}
     for k, v in kern.items():
         per_step[name_of.get(k, k)] = per_step.get(name_of.get(k, k), 0.0) + v["total_ms_per_step"]
-    dominant = max(per_step, key=per_step.get) if per_step else None
+    # dominant kernel: by the time its launches need with the chip to themselves where that pass ran (the timed region's per-kernel GPU time also counts
+    # the time a launch's waves wait for room beside the other frames' persistent grids: k_shade's 0.21 ms become 0.9-1.0 there, level with closest hit)
+    alone_named = {}
+    for k, v in (alone or {}).items():          # the item launch belongs to the shadow-ray walk (per_kernel groups them the same way)
+        if v: alone_named[{"k_trace_items": "k_trace_any"}.get(name_of.get(k, k), name_of.get(k, k))] = alone_named.get({"k_trace_items": "k_trace_any"}.get(name_of.get(k, k), name_of.get(k, k)), 0.0) + v
+    dominant = max(alone_named, key=alone_named.get) if alone_named else (max(per_step, key=per_step.get) if per_step else None)
     traffic = traffic_src = tj = None
     tfiles = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
     if tfiles:
@@ -216,7 +222,8 @@ def build_roofline(args, sc, work, stats, level0_rays, kern, alone, ms_per_step,
             "gpu_ms_per_step_by_kernel": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
             "definition": "achieved = (AABB::intersect calls + triangle tests x their cost in box tests, closest-hit and shadow rays of one frame, the reference's own counts at "
                           "SIMD_LANE_SIZE 1) / ms_per_step; peak = the chip's rate for that arithmetic with every operand in registers (experiments/slab_rate, 17 VALU per box test); "
-                          "kernel = most GPU time per step in the timed region; per_kernel fractions use each kernel's time per frame ALONE on the chip"}
+                          "kernel = most time per frame ALONE on the chip (gpu_ms_per_step_by_kernel: GPU time in the timed region, where a launch also waits for room beside other frames' grids); "
+                          "per_kernel fractions use each kernel's time per frame ALONE on the chip"}
     if not peak:
         return roof
     slab_peak, tri_peak, peak_src = peak

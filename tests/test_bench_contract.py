@@ -29,9 +29,10 @@ def test_committed_bench_line_has_the_contract_fields():
     assert j["parity"] == {"max_abs_rgb_vs_oracle": 0.0, "pixels_differing": 0, "packed_mismatch": 0, "stats_equal": True}
     assert abs(j["value"] - j["rays_per_frame"]["total"] / (j["ms_per_step"] * 1e-3) * 1e-6) / j["value"] < 1e-3
     if os.path.basename(_newest()) >= "r03":
-        # round 3: ONE statement — the headline is the whole frame's traversal work over ms_per_step, the dominant kernel is named by GPU time,
+        # round 3: ONE statement — the headline is the whole frame's traversal work over ms_per_step, the dominant kernel is the one that needs the most
+        # time with the chip to itself (earlier round-3 lines: the most GPU time in the timed region, where k_shade's waiting for room counts too),
         # every per-kernel fraction sits on the alone-on-chip denominator, the traffic says which sources it was measured on
-        assert r["kernel"] == max(r["gpu_ms_per_step_by_kernel"], key=r["gpu_ms_per_step_by_kernel"].get)
+        assert r["kernel"] in (max(r["per_kernel"], key=lambda k: r["per_kernel"][k]["ms_per_frame_alone"]), max(r["gpu_ms_per_step_by_kernel"], key=r["gpu_ms_per_step_by_kernel"].get))
         assert abs(r["achieved"] - r["units_per_frame"] / (j["ms_per_step"] * 1e-3) * 1e-9) / r["achieved"] < 1e-3
         assert r["traffic"] > 0 and isinstance(r["traffic_measured_on_these_sources"], bool)
         for k, v in r["per_kernel"].items():
@@ -71,7 +72,9 @@ def test_roofline_arithmetic_on_known_inputs(monkeypatch):
     args = types.SimpleNamespace(no_extras=False)
     r = bench.build_roofline(args, sc, work, stats, 900, kern, alone, 1.25, [900, 3000, 100, 0, 4000])
     units_c, units_a = 40e6 + 2.5 * 4e6, 100e6 + 2.5 * 8e6
-    assert r["kernel"] == "k_trace_closest"                                       # 1.2 ms of GPU time per step, the most
+    assert r["kernel"] == "k_trace_closest"                                       # 0.8 ms per frame alone on the chip, the most (shadow rays: 0.4 + 0.1)
+    alone2 = dict(alone, k_trace_any=0.6, k_trace_items=0.3)
+    assert bench.build_roofline(args, sc, work, stats, 900, kern, alone2, 1.25, [900, 3000, 100, 0, 4000])["kernel"] == "k_trace_any"      # packet + item launch together
     assert abs(r["achieved"] - (units_c + units_a) / 1.25e-3 * 1e-9) < 0.01 and abs(r["frac"] - r["achieved"] / 2000.0) < 1e-4
     pk = r["per_kernel"]
     assert abs(pk["k_trace_closest"]["frac"] - units_c / 0.8e-3 * 1e-9 / 2000.0) < 1e-3
