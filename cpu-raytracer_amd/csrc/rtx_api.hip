@@ -779,7 +779,13 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
     plan_batch(c, tile_count, batch_tiles);
     int rc = alloc_queues(c, batch_tiles);
     if (rc) return rc;
-    const int levels = c->cfg.bounces + 1;
+    // Levels that can hold rays: a hit spawns a reflection / refraction ray only where its material's Ks / Kt is not all zero (Raytracer.cpp:204-213,
+    // rtx_shade.h reflection_mask / refraction_mask).  With no such material uploaded the levels >= 1 are provably empty, and their
+    // launches — three per level, each a floor of 7-9 us — are not queued (BASELINE configs[1]: diffuse Monkey.obj with NUMBER_OF_BOUNCES 3).
+    bool can_spawn = false;
+    for (const rtx_material & m : c->h_materials)
+        for (int a = 0; a < 3; a++) if (m.reflection[a] != 0.0f || m.transmittance[a] != 0.0f) can_spawn = true;      // != is true for NaN too: conservative
+    const int levels = can_spawn ? c->cfg.bounces + 1 : 1;
     const int stream_blocks = c->n_cu * 8;          // k_resolve (256 threads)
     const int shade_blocks = c->n_cu * c->knobs.shade_grid;      // k_shade (RTX_SHADE_BLOCK = 256 threads, 3 resident blocks per CU at 168 VGPRs)
     const int pk_waves_closest = c->pk_blocks_closest * (RTX_PK_BLOCK / RTX_WAVE);

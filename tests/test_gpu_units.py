@@ -338,3 +338,31 @@ def test_deep_degenerate_blas_stacks_of_the_closest_hit_walk(api, shape, n, orde
         assert out["stats"] == ref["stats"], mode
         assert util.bit_exact(out["rgb"], ref["rgb"]) and np.array_equal(out["packed"], ref["packed"]), mode
     assert int(ref["stats"]["reflection"]) > 0
+
+
+def test_levels_that_cannot_hold_rays_are_not_launched(api):
+    """A hit spawns a reflection / refraction ray only where its material's Ks / Kt is not all zero (Raytracer.cpp:204-213).  With no such material
+    uploaded the levels >= 1 are provably empty whatever NUMBER_OF_BOUNCES says, and rtx_render_tiles queues one level's launches instead of four
+    levels' (three launches of 7-9 us each per level).  Same frame, same ray counts; with one reflective material back, all levels are launched."""
+    import copy
+    import orc
+    sc, _ = util.load_golden("monkey_small")
+    sc = copy.deepcopy(sc)
+    assert int(sc.config["bounces"][0] if hasattr(sc.config["bounces"], "__len__") else sc.config["bounces"]) == 3
+    launches = {}
+    for tag, ks in (("diffuse", 0.0), ("mirror", 0.25)):
+        sc.materials["reflection"][:] = ks; sc.materials["transmittance"][:] = 0.0
+        ref = orc.OracleScene(sc).render(threads=8)
+        r = api.Renderer(sc)
+        r.render(serial=True)
+        r.enable_timing(True)
+        out = r.render(serial=True)
+        names = [k for k, _ in r.kernel_times()]
+        r.enable_timing(False)
+        launches[tag] = names
+        assert out["stats"] == ref["stats"] and util.bit_exact(out["rgb"], ref["rgb"]) and np.array_equal(out["packed"], ref["packed"]), tag
+        for mode in ({}, {"lane_trace": True}, {"simple_trace": True}):
+            o2 = api.Renderer(sc).render(**mode)
+            assert o2["stats"] == ref["stats"] and util.bit_exact(o2["rgb"], ref["rgb"]), (tag, mode)
+    assert launches["diffuse"].count("k_shade") == 1 and launches["diffuse"].count("k_resolve") == 1 and launches["diffuse"].count("k_trace_closest") == 1, launches["diffuse"]
+    assert launches["mirror"].count("k_shade") == 4 and launches["mirror"].count("k_resolve") == 4 and launches["mirror"].count("k_trace_closest") == 4, launches["mirror"]
