@@ -59,7 +59,7 @@ struct Knobs {
     int split_items;             // RTX_PK_SPLIT           split shadow-ray walk: 0 = off, else the smallest item chunk
     int resolve_block;           // RTX_RESOLVE_BLOCK      k_resolve workgroup size
     int pk4_order;               // RTX_PK4_ORDER          slot order of the 4-wide records (0: smallest stack need first)
-    bool merge_any, no_wide, no_wide_closest, fail_item_alloc;
+    bool merge_any, no_wide, no_wide_closest, fail_item_alloc, graph;
     bool fuse_shade;             // RTX_FUSE_SHADE         the closest-hit packet kernel shades its own hits (0: a k_shade launch per level)
 };
 
@@ -105,6 +105,8 @@ struct rtx_ctx {
 
     bool timing = false;
     bool serial = false;                 // RTX_RENDER_SERIAL: keep every kernel on one stream (per-kernel timings without overlap)
+    // RTX_GRAPH=1: the launches of a rtx_render_tiles call are captured once into a hipGraph and replayed while nothing they depend on changes
+    hipGraphExec_t graph_exec = nullptr; std::vector<unsigned char> graph_key, graph_warm;
     std::vector<KernelTime> times;
     std::vector<hipEvent_t> event_pool;
     size_t event_next = 0;
@@ -337,6 +339,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     K.pk4_order = (int)knob_int("RTX_PK4_ORDER", 1, 0, 1);
     K.merge_any = knob_int("RTX_SERIAL_MERGE_ANY", 1, 0, 1) != 0;       // one-stream mode: ONE shadow-ray launch for all levels after the last shade (0: one per level)
     K.no_wide = knob_int("RTX_PK_WIDE", 1, 0, 1) == 0;                  // 0: binary shadow-ray walk for every mesh
+    K.graph = knob_int("RTX_GRAPH", 0, 0, 1) != 0;                      // 1: identical rtx_render_tiles calls replay a captured hipGraph
     K.no_wide_closest = knob_int("RTX_PK_WIDE_CLOSEST", 1, 0, 1) == 0;  // 0: binary per-lane phase of the closest-hit walk for every mesh
     K.fuse_shade = knob_int("RTX_FUSE_SHADE", 0, 0, 1) != 0;      // measured: 1.51 vs 1.28 ms per cfg3 frame with three frames in flight: off
     K.fail_item_alloc = knob_int("RTX_DEBUG_FAIL_ITEM_ALLOC", 0, 0, 1) != 0;      // tests: the item buffer's allocation fails (a size no device has), the fallback kernel must take over
@@ -400,6 +403,7 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     for (DevCounters * h : c->pending_host) hipHostFree(h);
     for (auto & st : c->stage) { if (st.host) hipHostFree(st.host); if (st.done) hipEventDestroy(st.done); }
+    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
     if (c->any_stream) { hipStreamSynchronize(c->any_stream); hipStreamDestroy(c->any_stream); }
     if (c->ev_shade0) hipEventDestroy(c->ev_shade0);
     if (c->ev_shade_last) hipEventDestroy(c->ev_shade_last);
@@ -824,6 +828,26 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         }
     }
 
+    // hipGraph replay: the kernel arguments of a call are functions of (scene, queues, tile range, flags, knobs); while those bytes stay the same the
+    // captured graph IS the call.  Only for single-batch calls without per-kernel timing.
+    bool capturing = false;
+    if (c->knobs.graph && !c->timing && tile_count <= batch_tiles) {
+        std::vector<unsigned char> key(sizeof(DevScene) + sizeof(DevQueues) + 5 * sizeof(int32_t) + sizeof(void *));
+        unsigned char * kp = key.data();
+        memcpy(kp, &c->scene, sizeof(DevScene)); kp += sizeof(DevScene); memcpy(kp, &c->q, sizeof(DevQueues)); kp += sizeof(DevQueues);
+        const int32_t kv[5] = { first_tile, tile_stride, tile_count, (int32_t)flags, levels }; memcpy(kp, kv, sizeof(kv)); kp += sizeof(kv);
+        memcpy(kp, &tile_major, sizeof(void *));
+        if (c->graph_exec && key == c->graph_key) {
+            HIP_OK(c, hipGraphLaunch(c->graph_exec, c->stream));
+            c->stats_pending = true;
+            return RTX_OK;
+        }
+        if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+        if (c->graph_warm == key) {           // second identical call: capture (the first one ran eagerly: lazy allocations, stream creation)
+            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) { capturing = true; c->graph_key = key; }
+            else hipGetLastError();
+        } else c->graph_warm = key;
+    }
     for (int done = 0; done < tile_count; done += batch_tiles) {
         const int n = (tile_count - done) < batch_tiles ? (tile_count - done) : batch_tiles;
         DevQueues q = c->q;
@@ -941,6 +965,14 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         if (overlap) { hipEventRecord(c->ev_any_done, c->any_stream); hipStreamWaitEvent(c->stream, c->ev_any_done, 0); }
         for (int level = levels - 1; level >= 0; level--)
             launch_timed(c, "k_resolve", c->stream, [&] { hipLaunchKernelGGL(k_resolve, dim3(level_blocks(level, stream_blocks) * (256 / c->knobs.resolve_block)), dim3(c->knobs.resolve_block), 0, c->stream, sc, q, level); });
+    }
+    if (capturing) {
+        hipGraph_t g = nullptr;
+        if (hipStreamEndCapture(c->stream, &g) != hipSuccess || !g) { hipGetLastError(); c->graph_key.clear(); c->err = "hipGraph capture failed"; return RTX_ERR_HIP; }
+        hipError_t e = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) { hipGetLastError(); c->graph_exec = nullptr; c->graph_key.clear(); c->err = "hipGraphInstantiate failed"; return RTX_ERR_HIP; }
+        HIP_OK(c, hipGraphLaunch(c->graph_exec, c->stream));
     }
     HIP_OK(c, hipGetLastError());
     c->stats_pending = true;
