@@ -112,7 +112,7 @@ int rtxh_texture_mips(float * texels_rgb, int32_t width, int32_t height, rtx_tex
  * but this loader does not (JPEG, BMP, GIF, PSD, PIC, PNM, HDR), RTX_ERR_INVALID_ARG for a corrupt file (the reference aborts). */
 int rtxh_texture_load(const char * path, int32_t mipmap_mode, float ** texels_out, int64_t * texel_count_out, rtx_texture_desc * desc);
 int rtxh_texture_free(float * texels);
-/* Sky::Sky (Sky.cpp:8-26): reads a square angular-map probe stored as raw float3 texels (`Data/Sky_Probes/*.float`); the result goes to
+/* Sky::Sky (Sky.cpp:8-26): reads a square angular-map probe stored as raw float3 texels (`Data/Sky_Probes/<name>.float`); the result goes to
  * rtx_upload_sky.  *texels_out is malloc'ed (free with rtxh_texture_free).  A file whose texel count is not a square is refused.     */
 int rtxh_sky_load(const char * path, float ** texels_out, int32_t * size_out);
 /* The decode step alone: width*height RGBA8 pixels, top row first (malloc'ed; free with rtxh_image_free). */
