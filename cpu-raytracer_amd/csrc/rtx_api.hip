@@ -59,7 +59,7 @@ struct Knobs {
     int split_items;             // RTX_PK_SPLIT           split shadow-ray walk: 0 = off, else the smallest item chunk
     int resolve_block;           // RTX_RESOLVE_BLOCK      k_resolve workgroup size
     int pk4_order;               // RTX_PK4_ORDER          slot order of the 4-wide records (0: smallest stack need first)
-    bool merge_any, no_wide, no_wide_closest, fail_item_alloc, graph;
+    bool merge_any, no_wide, no_wide_closest, fail_item_alloc, graph; int lpt;
     bool fuse_shade;             // RTX_FUSE_SHADE         the closest-hit packet kernel shades its own hits (0: a k_shade launch per level)
 };
 
@@ -107,6 +107,8 @@ struct rtx_ctx {
     bool serial = false;                 // RTX_RENDER_SERIAL: keep every kernel on one stream (per-kernel timings without overlap)
     // RTX_GRAPH=1: the launches of a rtx_render_tiles call are captured once into a hipGraph and replayed while nothing they depend on changes
     hipGraphExec_t graph_exec = nullptr; std::vector<unsigned char> graph_key, graph_warm;
+    // RTX_PK_LPT: level-0 closest-hit packets longest first, by their cost in the previous call with the same tiles (k_packet_order on a side stream)
+    DevBuf d_pk_cost, d_pk_order; hipStream_t order_stream = nullptr; hipEvent_t ev_cost = nullptr, ev_order = nullptr; int32_t lpt_key[4] = { -1, -1, -1, -1 }; bool lpt_valid = false;
     std::vector<KernelTime> times;
     std::vector<hipEvent_t> event_pool;
     size_t event_next = 0;
@@ -339,6 +341,7 @@ extern "C" int rtx_create(const rtx_config * config, rtx_ctx ** out_ctx) {
     K.pk4_order = (int)knob_int("RTX_PK4_ORDER", 1, 0, 1);
     K.merge_any = knob_int("RTX_SERIAL_MERGE_ANY", 1, 0, 1) != 0;       // one-stream mode: ONE shadow-ray launch for all levels after the last shade (0: one per level)
     K.no_wide = knob_int("RTX_PK_WIDE", 1, 0, 1) == 0;                  // 0: binary shadow-ray walk for every mesh
+    K.lpt = (int)knob_int("RTX_PK_LPT", -1, -1, 1);                     // level-0 closest-hit packets longest first (last frame's cost): 1 always, 0 never, -1: in the two-stream (one frame at a time) shape
     K.graph = knob_int("RTX_GRAPH", 0, 0, 1) != 0;                      // 1: identical rtx_render_tiles calls replay a captured hipGraph
     K.no_wide_closest = knob_int("RTX_PK_WIDE_CLOSEST", 1, 0, 1) == 0;  // 0: binary per-lane phase of the closest-hit walk for every mesh
     K.fuse_shade = knob_int("RTX_FUSE_SHADE", 0, 0, 1) != 0;      // measured: 1.51 vs 1.28 ms per cfg3 frame with three frames in flight: off
@@ -397,13 +400,14 @@ extern "C" int rtx_destroy(rtx_ctx * c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto & v : c->blas_allocs) for (void * p : v) hipFree(p);
     for (void * p : c->tex_allocs) if (p) hipFree(p);
-    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->d_frame, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads, &c->d_pk_fifo, &c->d_pk_items, &c->d_pk_item_count, &c->d_stats_partial, &c->d_dbg_s0, &c->d_dbg_s1 };
+    DevBuf * bufs[] = { &c->d_blas, &c->d_materials, &c->d_textures, &c->d_sky, &c->d_ewa, &c->d_frame, &c->d_counters, &c->d_spill, &c->d_fb_rgb, &c->d_fb_packed, &c->d_display, &c->d_gamma, &c->d_pk_heads, &c->d_pk_fifo, &c->d_pk_items, &c->d_pk_item_count, &c->d_stats_partial, &c->d_dbg_s0, &c->d_dbg_s1, &c->d_pk_cost, &c->d_pk_order };
     for (DevBuf * b : bufs) if (b->p) hipFree(b->p);
     for (DevBuf & b : c->qb) if (b.p) hipFree(b.p);
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     for (DevCounters * h : c->pending_host) hipHostFree(h);
     for (auto & st : c->stage) { if (st.host) hipHostFree(st.host); if (st.done) hipEventDestroy(st.done); }
     if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->order_stream) { hipStreamSynchronize(c->order_stream); hipStreamDestroy(c->order_stream); hipEventDestroy(c->ev_cost); hipEventDestroy(c->ev_order); }
     if (c->any_stream) { hipStreamSynchronize(c->any_stream); hipStreamDestroy(c->any_stream); }
     if (c->ev_shade0) hipEventDestroy(c->ev_shade0);
     if (c->ev_shade_last) hipEventDestroy(c->ev_shade_last);
@@ -724,6 +728,20 @@ static hipEvent_t next_event(rtx_ctx * c) {
     return c->event_pool[c->event_next++];
 }
 
+// Packets by descending cost: a counting sort over 256 linear cost classes in ONE workgroup (32 400 packets at 1080p: ~10 us, on a side stream).
+// The order inside a class is whatever the atomics make it — it is a schedule, not a result.
+__global__ __launch_bounds__(1024) void k_packet_order(const uint32_t * __restrict__ cost, uint32_t * __restrict__ order, const uint32_t n) {
+    __shared__ uint32_t hist[256], base[256];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    auto cls = [](uint32_t c) { const uint32_t k = c >> 7; return 255u - (k < 255u ? k : 255u); };      // class 0 = the most expensive
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[cls(cost[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t acc = 0; for (int k = 0; k < 256; k++) { base[k] = acc; acc += hist[k]; } }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&base[cls(cost[i])], 1u)] = i;
+}
+
 template <typename F>
 static void launch_timed(rtx_ctx * c, const char * name, hipStream_t stream, F && launch) {
     if (c->timing) {
@@ -830,6 +848,26 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
 
     // hipGraph replay: the kernel arguments of a call are functions of (scene, queues, tile range, flags, knobs); while those bytes stay the same the
     // captured graph IS the call.  Only for single-batch calls without per-kernel timing.
+    // RTX_PK_LPT: the level-0 closest-hit launch takes its packets longest first, by what the same packets cost in the previous call of this context
+    // over the same tiles (costs written by the launch itself, sorted by k_packet_order on a side stream while the rest of the frame runs).
+    // Measured (cfg3): the launch 309 -> 223 us alone, one frame at a time 1.48 -> 1.41 ms; with three frames in flight the tail it removes was
+    // being filled by the other frames' kernels anyway (1.090 -> 1.098 ms), and a launch with one packet per wave has nothing to reorder: so by default only
+    // in the two-stream shape and with at least two packets per wave.
+    const uint32_t lpt_n = (uint32_t)tile_count * 16u;
+    const bool lpt_want = c->knobs.lpt > 0 || (c->knobs.lpt < 0 && !c->serial && lpt_n >= 2u * (uint32_t)pk_waves_closest);
+    const bool lpt = lpt_want && !c->knobs.graph && tile_count <= batch_tiles && !count_work && !simple && !lane && !pstat && !c->scene.heatmap && !c->knobs.fuse_shade;
+    c->q.pk_cost = nullptr; c->q.pk_lpt_order = nullptr;
+    if (lpt) {
+        int lrc = ensure(c, c->d_pk_cost, (size_t)lpt_n * 4); if (!lrc) lrc = ensure(c, c->d_pk_order, (size_t)lpt_n * 4);
+        if (lrc) return lrc;
+        if (!c->order_stream) { HIP_OK(c, hipStreamCreateWithFlags(&c->order_stream, hipStreamNonBlocking)); hipEventCreateWithFlags(&c->ev_cost, hipEventDisableTiming); hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming); }
+        const int32_t key[4] = { first_tile, tile_stride, tile_count, levels };
+        const bool use_order = c->lpt_valid && memcmp(key, c->lpt_key, sizeof(key)) == 0;
+        memcpy(c->lpt_key, key, sizeof(key));
+        c->q.pk_cost = (uint32_t *)c->d_pk_cost.p;
+        if (use_order) { c->q.pk_lpt_order = (const uint32_t *)c->d_pk_order.p; hipStreamWaitEvent(c->stream, c->ev_order, 0); }
+        else if (c->lpt_valid) hipStreamWaitEvent(c->stream, c->ev_order, 0);      // the previous call's sort still reads the cost buffer
+    } else c->lpt_valid = false;
     bool capturing = false;
     if (c->knobs.graph && !c->timing && tile_count <= batch_tiles) {
         std::vector<unsigned char> key(sizeof(DevScene) + sizeof(DevQueues) + 5 * sizeof(int32_t) + sizeof(void *));
@@ -939,6 +977,12 @@ static int render_tiles_impl(rtx_ctx * c, int32_t first_tile, int32_t tile_strid
         };
         for (int level = 0; level < levels; level++) {
             launch_closest(level);
+            if (lpt && level == 0) {
+                hipEventRecord(c->ev_cost, c->stream); hipStreamWaitEvent(c->order_stream, c->ev_cost, 0);
+                hipLaunchKernelGGL(k_packet_order, dim3(1), dim3(1024), 0, c->order_stream, (const uint32_t *)c->d_pk_cost.p, (uint32_t *)c->d_pk_order.p, lpt_n);
+                hipEventRecord(c->ev_order, c->order_stream);
+                c->lpt_valid = true;
+            }
             if (!level_is_fused(level)) launch_timed(c, "k_shade", c->stream, [&] {
                 const int g = level_blocks(level, shade_blocks);
                 if (count_work) hipLaunchKernelGGL((k_shade<true, false>),  dim3(g), dim3(RTX_SHADE_BLOCK), 0, c->stream, sc, q, level);

@@ -164,6 +164,8 @@ struct DevQueues {
     uint32_t *    stats_partial;  // [level][stats_stride][4]: partial ray tallies of the level's shading pass, summed by k_resolve(level 0) (no atomics at the end of the pass)
     int32_t       stats_stride;   // entries reserved per level
     int32_t       stats_n[RTX_MAX_LEVELS + 1];     // entries the level's pass writes: k_shade one per workgroup, the fused packet kernel one per wave
+    uint32_t *       pk_cost;     // level-0 closest-hit packets: what each packet cost this frame (wave clock ticks >> 6), or null
+    const uint32_t * pk_lpt_order;    // ... and the order to take them in: last frame's packets by descending cost (k_packet_order), or null = queue order
     uint32_t *    pk_heads;       // packet-queue heads of the packet kernels: [closest | any][level][8 heads], 128 bytes apart (rtx_packet.h)
     uint32_t *    tm_packed;      // group rendering: level-0 pixels go, packed, to tm_packed[tm_base + primary slot] (tile-major) instead of the raster framebuffer
     int32_t       tm_base;

@@ -1872,6 +1872,10 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
 #ifdef RTX_LANE_PROF
         lp_had_packet = true;
 #endif
+        // level-0 closest-hit packets: longest first, by what the same packet cost in the previous frame of this context (scheduling only: a wave that
+        // draws a 600 us packet last sets the launch's tail)
+        const unsigned long long pk_t_start = (!ANY && level == 0 && q.pk_cost) ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (!ANY && level == 0 && q.pk_lpt_order) pk = (uint32_t)rfl((int)q.pk_lpt_order[pk]);
         // shadow-ray launches walk their packets last level first: the packets of the deeper levels are the incoherent, expensive ones
         // (longest jobs first: 0.79 -> 0.73 ms for the merged launch); RTX_PK_ORDER=0 restores queue order
         if (ANY && q.pk_order != 0) pk = npk - 1u - pk;
@@ -1983,6 +1987,7 @@ void k_packet(const DevScene sc, const DevQueues q, const int level, const int l
         }
         else if (W.valid) { q.h0[out_slot] = make_float4(W.ray.tcur, W.best_u, W.best_v, as_f(W.best_prim)); q.h1[out_slot] = W.best_tri; }
         else if (clipped) { q.h0[out_slot] = make_float4(INFINITY, 0.0f, 0.0f, as_f(PRIM_NONE)); q.h1[out_slot] = -1; }   // clipped pixel: never shaded
+        if (!ANY && level == 0 && q.pk_cost && lane == 0) q.pk_cost[pk] = (uint32_t)((__builtin_amdgcn_s_memtime() - pk_t_start) >> 6);
     }
     if (!ANY && FUSE && chunk_next < chunk_end) {      // the unused tail of this wave's last chunk (< RTX_PK_CHUNK slots): no ray there
         const uint32_t dead = chunk_next + (uint32_t)lane;

@@ -365,3 +365,27 @@ def test_closest_hit_walk_variants_change_nothing(api, name, knobs, monkeypatch)
     for mode in ({}, {"serial": True}, {"serial": True, "cull_dead_shadow_rays": True}):
         cmp = util.compare_to_golden(r.render(**mode), g)
         assert cmp["stats_equal"] and cmp["max_abs"] == 0.0 and cmp["n_diff_pixels"] == 0 and cmp["packed_mismatch"] == 0, (knobs, mode, cmp)
+
+
+@pytest.mark.parametrize("lpt", ["1", "-1", "0"])
+@pytest.mark.parametrize("name", ["materials_aniso", "dynamic", "tori16", "monkey_small"])
+def test_longest_packets_first_changes_nothing(api, name, lpt, monkeypatch):
+    """RTX_PK_LPT: from the second call over the same tiles on, the level-0 closest-hit launch takes its packets longest first, by what each packet
+    cost in the previous call (costs written by the launch, sorted on a side stream: csrc/rtx_api.hip k_packet_order).  A schedule, not a result:
+    every frame of a series — the first (queue order), the later ones (sorted), after a change of tile range and back — is the reference's, in both
+    launch shapes; 1 = always, -1 = the default rule (two-stream shape, at least two packets per wave), 0 = never."""
+    monkeypatch.setenv("RTX_PK_LPT", lpt)
+    sc, g = util.load_golden(name)
+    r = api.Renderer(sc)
+    for mode in ({}, {"serial": True}, {}):
+        for i in range(4):
+            cmp = util.compare_to_golden(r.render(**mode), g)
+            assert cmp["stats_equal"] and cmp["max_abs"] == 0.0 and cmp["n_diff_pixels"] == 0 and cmp["packed_mismatch"] == 0, (mode, i, cmp)
+    half = sc.tile_count // 2
+    for i in range(3):                      # another tile range: its own history; the rest of the frame keeps the earlier pixels
+        r.render_async(0, 1, half)
+    for i in range(3):
+        r.render_async(half, 1, sc.tile_count - half)
+    r.synchronize()
+    _, packed = r.framebuffer()
+    assert np.array_equal(packed, np.asarray(g["packed"]).reshape(packed.shape))
